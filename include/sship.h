@@ -1,0 +1,214 @@
+/* sship.h - C ABI of libsuperslam_hip.so: the MI355X (gfx950) deep-feature front-end for SuperSLAM.
+ *
+ * This header is the drop-in boundary.  Every entry point replaces a piece of the reference's
+ * TensorRT/CUDA inference layer (paths relative to /root/reference); the C++ adapter a maintainer adds
+ * on the reference side (classes SuperPoint / LightGlue implementing IFeatureExtractor / IFeatureMatcher
+ * over these calls) is shown in INTEGRATION.md and shipped as include/superslam_hip/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch/OpenCV types cross the ABI;
+ *   - every function returns an int status (0 = SSHIP_OK); nothing throws or longjmps across the ABI;
+ *     sship_last_error() returns a thread-local message for the last non-zero status;
+ *   - "_dev" pointers are HIP device pointers, all others host pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream);
+ *   - external dtypes follow the reference engines (scripts/rebuild_engines.sh:85-92,108-115):
+ *     image u8 (normalised to [0,1] on device), scores f32, descriptors f16, kpts f32,
+ *     matches0 i32, mscores0 f32.  Internal accumulation is f32.
+ *   - handles are single-threaded; sship_lg_weights is immutable and shareable across handles/threads
+ *     (the LightGlueEngine / shared_engine() analogue, include/LightGlue.h:28-31,44).
+ */
+#ifndef SSHIP_H_
+#define SSHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSHIP_VERSION 100
+#define SSHIP_DESC_DIM 256 /* include/SuperPoint.h:76 descriptor_dim */
+
+typedef enum {
+  SSHIP_OK = 0,
+  SSHIP_ERR_INVALID = 1,        /* bad argument */
+  SSHIP_ERR_HIP = 2,            /* HIP runtime failure */
+  SSHIP_ERR_IO = 3,             /* weights file missing / malformed */
+  SSHIP_ERR_NOMEM = 4,
+  SSHIP_ERR_POOL_EXHAUSTED = 5, /* src/SuperPoint.cc:724-727 */
+  SSHIP_ERR_NO_DEVICE = 6       /* no gfx950 device: the library never falls back to the CPU */
+} sship_status;
+
+/* ------------------------------------------------------------------------------------------------
+ * Runtime
+ * ---------------------------------------------------------------------------------------------- */
+/* Select the HIP device (replaces the implicit cudaSetDevice(0) of SuperPoint::initialize,
+ * src/SuperPoint.cc:38-67).  Fails with SSHIP_ERR_NO_DEVICE when no GPU is visible. */
+int sship_init(int device);
+int sship_version(void);
+const char* sship_last_error(void);
+/* level: 0 trace .. 4 error; the adapter forwards to SLOG_* (include/Logging.h:21-26). */
+void sship_set_log_callback(void (*cb)(int level, const char* msg));
+int sship_device_synchronize(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Descriptor pool - include/DescriptorPool.h:13-91, src/DescriptorPool.cc:10-38
+ * N device slots of max_keypoints*dim fp16; LIFO free-list (FreeList, DescriptorPool.h:25-44).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sship_pool sship_pool;
+int sship_pool_create(int num_slots, int max_keypoints, int dim, sship_pool** out);
+void sship_pool_destroy(sship_pool* pool);
+int sship_pool_acquire(sship_pool* pool);            /* FreeList::acquire: slot index or -1 when exhausted */
+void sship_pool_release(sship_pool* pool, int slot); /* FreeList::release */
+int sship_pool_in_use(const sship_pool* pool);       /* FreeList::in_use */
+void* sship_pool_slot_ptr(const sship_pool* pool, int slot); /* DescriptorPool::slot_ptr (NULL if out of range) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Descriptor gather - 1:1 with launch_gather_descriptors, include/DescriptorGather.h:12-20,
+ * src/DescriptorGather.cu:14-82.  grid_fp16_dev is [channels, grid_h, grid_w] (CHW) fp16; cell_h/cell_w
+ * are device int arrays; out is [num_keypoints, channels] fp16, each row L2-normalised
+ * (fp32 sum of squares, rsqrt(sum + 1e-12), round-to-nearest fp16).  num_keypoints <= 0 is a no-op.
+ * The _hwc variant reads a channels-last grid [grid_h, grid_w, channels] (one contiguous 512-B row per
+ * keypoint - the layout the HIP SuperPoint produces internally).
+ * ---------------------------------------------------------------------------------------------- */
+int sship_gather_normalize(const void* grid_fp16_dev, int channels, int grid_h, int grid_w,
+                           const int* cell_h_dev, const int* cell_w_dev, int num_keypoints,
+                           void* out_fp16_dev, void* stream);
+int sship_gather_normalize_hwc(const void* grid_fp16_dev, int channels, int grid_h, int grid_w,
+                               const int* cell_h_dev, const int* cell_w_dev, int num_keypoints,
+                               void* out_fp16_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Detector post-processing stages (exposed so each can be parity-tested bit-exactly)
+ * ---------------------------------------------------------------------------------------------- */
+/* utils/convert_superpoint_to_onnx.py:82-87: pooled = max_pool2d(s, 2r+1, 1, r); s = (s==pooled)?s:0. */
+int sship_nms(const float* scores_dev, int batch, int h, int w, int radius, float* out_dev, void* stream);
+/* src/SuperPoint.cc:696-719 on one device score map: strict `score > thr` (thr is a double) inside the
+ * border, descending (score, h, w) order, first max_kp; kp (x = w*input_w/score_w, y = h*input_h/score_h,
+ * score) triples, cells = min(h/8, desc_h-1), min(w/8, desc_w-1).  All outputs are device arrays
+ * ([3*max_kp] f32, [max_kp] i32, [max_kp] i32, [1] i32); n_candidates_dev may be NULL. */
+int sship_select_topk(const float* scores_dev, int score_h, int score_w, int input_h, int input_w,
+                      double thr, int border, int max_kp, int desc_h, int desc_w, float* kp_xys_dev,
+                      int* cell_h_dev, int* cell_w_dev, int* n_dev, int* n_candidates_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SuperPoint extractor - include/SuperPoint.h:36-54, src/SuperPoint.cc
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sship_sp sship_sp;
+typedef struct {
+  const char* weights_path;  /* safetensors with the reference's state-dict keys (conv1a.weight ...).  Takes
+                                the place of SuperPoint's engine_file (src/SuperSLAM.cc:72-78). */
+  int max_keypoints;         /* superpoint.max_keypoints (600 in the KITTI YAML) */
+  double keypoint_threshold; /* superpoint.keypoint_threshold (0.005) */
+  int remove_borders;        /* superpoint.remove_borders (4) */
+  int nms_radius;            /* exporter --nms-radius (4) */
+  int pool_slots;            /* include/SuperPoint.h:77-78 descriptor_pool_slots (8); 0 -> 8 */
+  int max_batch;             /* images per call the workspaces are sized for (2 = stereo); 0 -> 2 */
+} sship_sp_config;
+
+/* One image's extraction result.  kp_xys is caller-owned [3*max_keypoints] (x, y, score per keypoint -
+ * cv::KeyPoint(x, y, 1, -1, score), src/SuperPoint.cc:715).  desc_dev points into pool slot `slot`
+ * ([n, 256] fp16 row-major, L2-normalised); the caller owns the slot and returns it with
+ * sship_pool_release(sship_sp_pool(sp), slot).  n == 0 -> slot = -1, desc_dev = NULL (success). */
+typedef struct {
+  float* kp_xys;
+  int n;
+  void* desc_dev;
+  int slot;
+} sship_features;
+
+int sship_sp_create(const sship_sp_config* cfg, sship_sp** out); /* ctor + initialize() */
+void sship_sp_destroy(sship_sp* sp);
+sship_pool* sship_sp_pool(sship_sp* sp);
+int sship_sp_max_keypoints(const sship_sp* sp);
+
+/* SuperPoint::extract (src/SuperPoint.cc:895-899 -> infer_device :597-676): host u8 image, 1 or 3 (BGR)
+ * channels, row stride in bytes.  Synchronous. */
+int sship_sp_extract(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels,
+                     sship_features* out);
+/* SuperPoint::extract_stereo (src/SuperPoint.cc:902-908 -> infer_device_stereo :754-892): one batch-2
+ * pass; the pair must share resolution (:762-765). */
+int sship_sp_extract_stereo(sship_sp* sp, const uint8_t* left, const uint8_t* right, int h, int w,
+                            int stride, int channels, sship_features* out_left, sship_features* out_right);
+/* SuperPoint::infer host path (src/SuperPoint.cc:322-348,427-528): keypoints + CV_32F [n,256] descriptors
+ * on the host.  kp_xys [3*max_kp], desc_f32 [max_kp*256]. */
+int sship_sp_infer_host(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels,
+                        float* kp_xys, float* desc_f32, int* n);
+
+/* Throughput path: `batch` grayscale u8 images already resident in HBM ([batch, h, w] contiguous); results
+ * stay on the device: desc [batch, max_kp, 256] f16, kp [batch, max_kp, 3] f32, n [batch] i32.
+ * Asynchronous on `stream`; no host synchronisation anywhere inside. */
+int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs_dev, int batch, int h, int w,
+                                  void* desc_out_dev, float* kp_out_dev, int* n_out_dev, void* stream);
+
+/* Dense outputs of the network, in the reference engine's layouts (scripts/rebuild_engines.sh:88-97):
+ * scores f32 [batch, 8*(h/8), 8*(w/8)] after NMS, descriptors f16 [batch, 256, h/8, w/8] (CHW,
+ * L2-normalised).  logits_dev (optional) receives the raw detector logits f32 [batch, 65, h/8, w/8].
+ * Any output pointer may be NULL. */
+int sship_sp_dense(sship_sp* sp, const uint8_t* imgs_dev, int batch, int h, int w, float* scores_dev,
+                   void* desc_grid_dev, float* logits_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LightGlue matcher - include/LightGlue.h:28-63, src/LightGlue.cc
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sship_lg_weights sship_lg_weights; /* LightGlueEngine analogue (refcounted, immutable) */
+typedef struct sship_lg sship_lg;
+
+int sship_lg_weights_load(const char* safetensors_path, sship_lg_weights** out);
+void sship_lg_weights_retain(sship_lg_weights* w);
+void sship_lg_weights_release(sship_lg_weights* w);
+
+/* LightGlue(engine, image_width, image_height) + initialize().  max_keypoints bounds n0/n1 (the reference
+ * engine's profile max is 1024, scripts/rebuild_engines.sh:118); max_pairs sizes the batched workspaces. */
+int sship_lg_create(sship_lg_weights* w, int image_width, int image_height, int max_keypoints,
+                    int max_pairs, sship_lg** out);
+void sship_lg_destroy(sship_lg* lg);
+
+/* Keypoint normalisation, src/LightGlue.cc:241-251: (pt - (W/2,H/2)) / (max(W,H)/2).  kp_xy has `stride`
+ * floats per keypoint (2 or 3); out is [n,2]. */
+int sship_lg_normalize_keypoints(const sship_lg* lg, const float* kp_xy, int stride, int n, float* out);
+
+/* Device match, src/LightGlue.cc:377-457: host keypoints (pixel coordinates, `kp_stride` floats apart),
+ * descriptors resident in pool slots ([n,256] fp16).  Outputs on the host: matches0 [n0] (index into set 1
+ * or -1), mscores0 [n0].  n0 == 0 or n1 == 0 -> SSHIP_ERR_INVALID (the reference returns an empty result). */
+int sship_lg_match_device(sship_lg* lg, const float* kp0, int kp_stride0, int n0, const void* desc0_dev,
+                          const float* kp1, int kp_stride1, int n1, const void* desc1_dev,
+                          int32_t* matches0, float* mscores0);
+/* Host-descriptor match, src/LightGlue.cc:285-324: CV_32F [n,256] descriptors, converted to fp16 and
+ * uploaded internally (the loop-closure overload). */
+int sship_lg_match_host(sship_lg* lg, const float* kp0, int kp_stride0, int n0, const float* desc0_f32,
+                        const float* kp1, int kp_stride1, int n1, const float* desc1_f32,
+                        int32_t* matches0, float* mscores0);
+/* Throughput path: `pairs` independent problems, everything device-resident and asynchronous.
+ * kp_dev [2*pairs, max_kp, 3] (pixel x, y, score), n_dev [2*pairs], desc_dev [2*pairs, max_kp, 256] f16,
+ * image 2p is set 0 and image 2p+1 is set 1 of pair p.  Outputs matches0_dev / mscores0_dev
+ * [pairs, max_kp]; rows >= n are -1 / 0. */
+int sship_lg_match_batch_device(sship_lg* lg, const float* kp_dev, const int* n_dev, const void* desc_dev,
+                                int pairs, int32_t* matches0_dev, float* mscores0_dev, void* stream);
+/* Match post-processing, src/LightGlue.cc:326-363: ascending i, skip -1, distance = 1 - score.
+ * Returns the number of matches (>= 0). */
+int sship_filter_matches(const int32_t* matches0, const float* mscores0, int n0, int* query_idx,
+                         int* train_idx, float* distance);
+/* LightGlue::descriptors_to_host, src/LightGlue.cc:460-475: fp16 [count, dim] device -> f32 host. */
+int sship_desc_to_host(const void* desc_dev, int count, int dim, float* out_f32);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused front-end step: what StereoFrontEnd::process asks of the two interfaces per frame
+ * (src/StereoFrontEnd.cc:14,33): SuperPoint on L and R (one batch) + gather x2 + one LightGlue match,
+ * for `pairs` stereo pairs at once, device-resident, no host synchronisation.  imgs_dev is
+ * [2*pairs, h, w] u8 ordered L0, R0, L1, R1, ...  Output shapes as in the two batch calls above.
+ * ---------------------------------------------------------------------------------------------- */
+int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs_dev, int pairs, int h, int w,
+                                void* desc_out_dev, float* kp_out_dev, int* n_out_dev,
+                                int32_t* matches0_dev, float* mscores0_dev, void* stream);
+
+/* Per-stage device timings (ms) of the last *_batch_device call made with profiling enabled
+ * (sship_set_profiling(1) inserts hipEvents; off by default).  Labels follow the reference's profile
+ * scopes (src/SuperPoint.cc:639,904; src/StereoFrontEnd.cc:13,32).  Returns the number of stages. */
+void sship_set_profiling(int on);
+int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSHIP_H_ */

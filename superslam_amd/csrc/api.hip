@@ -1,0 +1,1036 @@
+// C ABI of libsuperslam_hip.so (include/sship.h): weights, workspaces, streams and the launch sequences of
+// the SuperPoint extractor, the LightGlue matcher and the fused front-end step.  gfx950 only; there is no CPU
+// fallback anywhere in this library - without a GPU every entry point fails with SSHIP_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sship.h"
+#include "kernels.h"
+
+namespace sship {
+
+static thread_local std::string g_err;
+static void (*g_log_cb)(int, const char*) = nullptr;
+static bool g_profiling = false;
+
+void set_error(const std::string& msg) {
+  g_err = msg;
+  if (g_log_cb) g_log_cb(4, msg.c_str());
+}
+void log_msg(int level, const char* fmt, ...) {
+  if (!g_log_cb) return;
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_log_cb(level, buf);
+}
+static int fail(int code, const std::string& msg) {
+  set_error(msg);
+  return code;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device memory helper
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+struct PinBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; bytes = 0;
+    hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// safetensors reader (8-byte LE header length, JSON header, raw little-endian tensor data)
+// ------------------------------------------------------------------------------------------------
+struct Tensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
+};
+typedef std::map<std::string, Tensor> StateDict;
+
+static float half_bits_to_float(uint16_t h) {
+  const uint32_t s = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f;
+  uint32_t m = h & 0x3ffu, u;
+  if (e == 0) {
+    if (m == 0) u = s;
+    else {
+      int sh = 0;
+      while (!(m & 0x400u)) { m <<= 1; ++sh; }
+      u = s | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+  else u = s | ((e + 112) << 23) | (m << 13);
+  float f; memcpy(&f, &u, 4); return f;
+}
+
+static bool load_safetensors(const std::string& path, StateDict& sd, std::string& err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { err = "cannot open weights file '" + path + "'"; return false; }
+  uint64_t hlen = 0;
+  f.read(reinterpret_cast<char*>(&hlen), 8);
+  if (!f || hlen == 0 || hlen > (1ull << 28)) { err = "bad safetensors header in '" + path + "'"; return false; }
+  std::string js(hlen, '\0');
+  f.read(&js[0], (std::streamsize)hlen);
+  std::vector<char> blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  // Minimal parser for {"name": {"dtype": "F32", "shape": [..], "data_offsets": [a, b]}, ...}
+  size_t i = 0;
+  auto skip_ws = [&]() { while (i < js.size() && (js[i] == ' ' || js[i] == '\n' || js[i] == '\t' || js[i] == '\r')) ++i; };
+  auto parse_str = [&](std::string& out) -> bool {
+    skip_ws();
+    if (i >= js.size() || js[i] != '"') return false;
+    ++i; out.clear();
+    while (i < js.size() && js[i] != '"') { if (js[i] == '\\' && i + 1 < js.size()) ++i; out.push_back(js[i++]); }
+    ++i; return true;
+  };
+  auto skip_value = [&]() {  // skip a JSON value (used for __metadata__)
+    skip_ws();
+    int depth = 0; bool in_str = false;
+    for (; i < js.size(); ++i) {
+      const char c = js[i];
+      if (in_str) { if (c == '\\') ++i; else if (c == '"') in_str = false; continue; }
+      if (c == '"') in_str = true;
+      else if (c == '{' || c == '[') ++depth;
+      else if (c == '}' || c == ']') { if (--depth == 0) { ++i; return; } }
+      else if ((c == ',') && depth == 0) return;
+    }
+  };
+  skip_ws();
+  if (i >= js.size() || js[i] != '{') { err = "safetensors header is not an object"; return false; }
+  ++i;
+  while (true) {
+    skip_ws();
+    if (i < js.size() && js[i] == '}') break;
+    std::string name;
+    if (!parse_str(name)) { err = "safetensors header parse error"; return false; }
+    skip_ws();
+    if (js[i] != ':') { err = "safetensors header parse error (:)"; return false; }
+    ++i;
+    if (name == "__metadata__") { skip_value(); }
+    else {
+      skip_ws();
+      if (js[i] != '{') { err = "safetensors entry parse error"; return false; }
+      ++i;
+      std::string dtype; std::vector<int64_t> shape; uint64_t off0 = 0, off1 = 0;
+      while (true) {
+        skip_ws();
+        if (js[i] == '}') { ++i; break; }
+        std::string key;
+        if (!parse_str(key)) { err = "safetensors entry key parse error"; return false; }
+        skip_ws(); ++i;  // ':'
+        skip_ws();
+        if (key == "dtype") { parse_str(dtype); }
+        else if (key == "shape" || key == "data_offsets") {
+          ++i;  // '['
+          std::vector<int64_t> vals;
+          while (true) {
+            skip_ws();
+            if (js[i] == ']') { ++i; break; }
+            if (js[i] == ',') { ++i; continue; }
+            vals.push_back(strtoll(js.c_str() + i, nullptr, 10));
+            while (i < js.size() && (isdigit((unsigned char)js[i]) || js[i] == '-')) ++i;
+          }
+          if (key == "shape") shape = vals;
+          else if (vals.size() == 2) { off0 = (uint64_t)vals[0]; off1 = (uint64_t)vals[1]; }
+        } else skip_value();
+        skip_ws();
+        if (js[i] == ',') ++i;
+      }
+      Tensor t; t.shape = shape;
+      const size_t n = t.numel();
+      if (off1 > blob.size() || off1 < off0) { err = "tensor '" + name + "' exceeds file"; return false; }
+      t.data.resize(n);
+      if (dtype == "F32" && off1 - off0 == n * 4) memcpy(t.data.data(), blob.data() + off0, n * 4);
+      else if (dtype == "F16" && off1 - off0 == n * 2) {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(blob.data() + off0);
+        for (size_t k = 0; k < n; ++k) t.data[k] = half_bits_to_float(h[k]);
+      } else { err = "tensor '" + name + "': unsupported dtype " + dtype; return false; }
+      sd[name] = std::move(t);
+    }
+    skip_ws();
+    if (i < js.size() && js[i] == ',') ++i;
+  }
+  return true;
+}
+
+static const Tensor* find_tensor(const StateDict& sd, const std::string& name, std::initializer_list<int64_t> shape,
+                                 std::string& err) {
+  auto it = sd.find(name);
+  if (it == sd.end()) { err = "missing tensor '" + name + "'"; return nullptr; }
+  if (it->second.shape != std::vector<int64_t>(shape)) { err = "tensor '" + name + "' has the wrong shape"; return nullptr; }
+  return &it->second;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing into MFMA A-fragment order (igemm.h):
+//   [cout_blk][cin_chunk][ky][kx][kstep][mtile][lane][8]  with
+//   cout = cb*CT + mt*32 + (lane & 31),  cin = chunk*64 + ks*16 + (lane >> 5)*8 + e
+// `w` is [cout][cin][ks][ks] row-major (PyTorch Conv2d / Linear); row_map/scale allow host-side row
+// permutation and folding of constant factors.
+// ------------------------------------------------------------------------------------------------
+static int upload_conv(const float* w, const float* bias, int cout, int cin, int ks, int ct, ConvW& out,
+                       const std::vector<int>* row_map = nullptr, const std::vector<float>* row_scale = nullptr) {
+  const int cout_pad = (cout + ct - 1) / ct * ct, mt_n = ct / 32, nchunk = cin / 64;
+  std::vector<_Float16> pk((size_t)cout_pad * cin * ks * ks);
+  size_t o = 0;
+  for (int cb = 0; cb < cout_pad / ct; ++cb)
+    for (int ch = 0; ch < nchunk; ++ch)
+      for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx)
+          for (int kstep = 0; kstep < 4; ++kstep)
+            for (int mt = 0; mt < mt_n; ++mt)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                  const int co = cb * ct + mt * 32 + (lane & 31);
+                  const int ci = ch * 64 + kstep * 16 + (lane >> 5) * 8 + e;
+                  float v = 0.f;
+                  if (co < cout) {
+                    const int src = row_map ? (*row_map)[co] : co;
+                    v = w[(((size_t)src * cin + ci) * ks + ky) * ks + kx];
+                    if (row_scale) v *= (*row_scale)[co];
+                  }
+                  pk[o++] = (_Float16)v;
+                }
+  std::vector<float> bp(cout_pad, 0.f);
+  for (int co = 0; co < cout; ++co) {
+    const int src = row_map ? (*row_map)[co] : co;
+    bp[co] = bias ? bias[src] * (row_scale ? (*row_scale)[co] : 1.f) : 0.f;
+  }
+  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.w), pk.size() * sizeof(_Float16)));
+  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.bias), bp.size() * sizeof(float)));
+  SSHIP_HIP_CHECK(hipMemcpy(out.w, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  SSHIP_HIP_CHECK(hipMemcpy(out.bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  out.cin = cin; out.cout = cout; out.cout_pad = cout_pad; out.ks = ks; out.ct = ct;
+  return SSHIP_OK;
+}
+static void free_conv(ConvW& c) {
+  if (c.w) (void)hipFree(c.w);
+  if (c.bias) (void)hipFree(c.bias);
+  c.w = nullptr; c.bias = nullptr;
+}
+static int upload_floats(const float* src, size_t n, float** dst) {
+  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(float)));
+  SSHIP_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return SSHIP_OK;
+}
+
+static bool g_inited = false;
+static int require_device() {
+  if (g_inited) return SSHIP_OK;
+  return sship_init(-1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage timers (off by default)
+// ------------------------------------------------------------------------------------------------
+struct StageTimer {
+  std::vector<std::pair<const char*, hipEvent_t>> marks;
+  std::vector<std::pair<std::string, float>> last;
+  void begin(hipStream_t s) { if (!g_profiling) return; clear(); mark("start", s); }
+  void mark(const char* label, hipStream_t s) {
+    if (!g_profiling) return;
+    hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s); marks.push_back({label, e});
+  }
+  void clear() { for (auto& m : marks) (void)hipEventDestroy(m.second); marks.clear(); }
+  void collect() {
+    if (marks.size() < 2) return;
+    (void)hipEventSynchronize(marks.back().second);
+    last.clear();
+    for (size_t i = 1; i < marks.size(); ++i) {
+      float ms = 0.f; (void)hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
+      last.push_back({marks[i].first, ms});
+    }
+    clear();
+  }
+};
+static StageTimer g_timer;
+
+}  // namespace sship
+
+using namespace sship;
+
+// ====================================================================================================
+// runtime
+// ====================================================================================================
+extern "C" int sship_version(void) { return SSHIP_VERSION; }
+extern "C" const char* sship_last_error(void) { return g_err.c_str(); }
+extern "C" void sship_set_log_callback(void (*cb)(int, const char*)) { g_log_cb = cb; }
+extern "C" void sship_set_profiling(int on) { g_profiling = on != 0; }
+extern "C" int sship_get_stage_timings(const char** labels, float* ms, int max_stages) {
+  g_timer.collect();
+  int n = 0;
+  for (auto& kv : g_timer.last) {
+    if (n >= max_stages) break;
+    labels[n] = kv.first.c_str(); ms[n] = kv.second; ++n;
+  }
+  return n;
+}
+extern "C" int sship_init(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(SSHIP_ERR_NO_DEVICE, "no HIP device visible: libsuperslam_hip has no CPU path");
+  if (device < 0) {
+    const char* env = getenv("SUPERSLAM_HIP_DEVICE");
+    device = env ? atoi(env) : -1;
+  }
+  if (device >= 0) {
+    if (device >= count) return fail(SSHIP_ERR_INVALID, "device index out of range");
+    SSHIP_HIP_CHECK(hipSetDevice(device));
+  }
+  int cur = 0;
+  SSHIP_HIP_CHECK(hipGetDevice(&cur));
+  hipDeviceProp_t prop;
+  SSHIP_HIP_CHECK(hipGetDeviceProperties(&prop, cur));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SSHIP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  g_inited = true;
+  log_msg(2, "sship: device %d %s, %d CUs", cur, prop.gcnArchName, prop.multiProcessorCount);
+  return SSHIP_OK;
+}
+extern "C" int sship_device_synchronize(void) {
+  SSHIP_HIP_CHECK(hipDeviceSynchronize());
+  return SSHIP_OK;
+}
+
+// ====================================================================================================
+// descriptor pool  (include/DescriptorPool.h:13-91, src/DescriptorPool.cc:10-38)
+// ====================================================================================================
+struct sship_pool {
+  int max_keypoints = 0, dim = 0;
+  size_t slot_bytes = 0;
+  std::vector<void*> slots;
+  std::vector<int> free_slots;  // LIFO (FreeList)
+  std::mutex mu;                // handles may be released from another thread (async keyframe copies)
+};
+extern "C" int sship_pool_create(int num_slots, int max_keypoints, int dim, sship_pool** out) {
+  if (!out || num_slots <= 0 || max_keypoints <= 0 || dim <= 0) return fail(SSHIP_ERR_INVALID, "pool_create: bad arguments");
+  if (int rc = require_device()) return rc;
+  auto* p = new sship_pool();
+  p->max_keypoints = max_keypoints; p->dim = dim;
+  p->slot_bytes = (size_t)max_keypoints * dim * sizeof(_Float16);
+  p->slots.assign(num_slots, nullptr);
+  for (int i = num_slots - 1; i >= 0; --i) p->free_slots.push_back(i);  // DescriptorPool.h:27-29
+  for (int i = 0; i < num_slots; ++i)
+    if (hipMalloc(&p->slots[i], p->slot_bytes) != hipSuccess) {
+      sship_pool_destroy(p);
+      return fail(SSHIP_ERR_NOMEM, "pool_create: hipMalloc failed");
+    }
+  *out = p;
+  return SSHIP_OK;
+}
+extern "C" void sship_pool_destroy(sship_pool* pool) {
+  if (!pool) return;
+  for (void* s : pool->slots) if (s) (void)hipFree(s);
+  delete pool;
+}
+extern "C" int sship_pool_acquire(sship_pool* pool) {
+  if (!pool) return -1;
+  std::lock_guard<std::mutex> g(pool->mu);
+  if (pool->free_slots.empty()) return -1;
+  const int s = pool->free_slots.back();
+  pool->free_slots.pop_back();
+  return s;
+}
+extern "C" void sship_pool_release(sship_pool* pool, int slot) {
+  if (!pool || slot < 0 || slot >= (int)pool->slots.size()) return;
+  std::lock_guard<std::mutex> g(pool->mu);
+  pool->free_slots.push_back(slot);
+}
+extern "C" int sship_pool_in_use(const sship_pool* pool) {
+  if (!pool) return 0;
+  return (int)pool->slots.size() - (int)pool->free_slots.size();
+}
+extern "C" void* sship_pool_slot_ptr(const sship_pool* pool, int slot) {
+  if (!pool || slot < 0 || slot >= (int)pool->slots.size()) return nullptr;
+  return pool->slots[slot];
+}
+
+// ====================================================================================================
+// gather / nms / select stage entry points
+// ====================================================================================================
+extern "C" int sship_gather_normalize(const void* grid, int channels, int gh, int gw, const int* cell_h,
+                                      const int* cell_w, int n, void* out, void* stream) {
+  if (n <= 0) return SSHIP_OK;  // DescriptorGather.cu:69
+  if (!grid || !cell_h || !cell_w || !out || channels <= 0) return fail(SSHIP_ERR_INVALID, "gather_normalize: null argument");
+  if (int rc = require_device()) return rc;
+  launch_gather_chw(static_cast<const _Float16*>(grid), channels, gh, gw, cell_h, cell_w, n,
+                    static_cast<_Float16*>(out), static_cast<hipStream_t>(stream));
+  SSHIP_HIP_CHECK(hipGetLastError());
+  return SSHIP_OK;
+}
+extern "C" int sship_gather_normalize_hwc(const void* grid, int channels, int gh, int gw, const int* cell_h,
+                                          const int* cell_w, int n, void* out, void* stream) {
+  if (n <= 0) return SSHIP_OK;
+  if (!grid || !cell_h || !cell_w || !out) return fail(SSHIP_ERR_INVALID, "gather_normalize_hwc: null argument");
+  if (channels <= 0 || channels > 256 || channels % 4) return fail(SSHIP_ERR_INVALID, "gather_normalize_hwc: channels must be <= 256 and a multiple of 4");
+  if (int rc = require_device()) return rc;
+  launch_gather_hwc(false, static_cast<const _Float16*>(grid), channels, gh, gw, 0, cell_h, cell_w, nullptr, n, n, 1,
+                    static_cast<_Float16*>(out), static_cast<hipStream_t>(stream));
+  SSHIP_HIP_CHECK(hipGetLastError());
+  return SSHIP_OK;
+}
+extern "C" int sship_nms(const float* scores, int batch, int h, int w, int radius, float* out, void* stream) {
+  if (!scores || !out || batch <= 0 || h <= 0 || w <= 0) return fail(SSHIP_ERR_INVALID, "nms: bad arguments");
+  if (radius < 0 || radius > 8) return fail(SSHIP_ERR_INVALID, "nms: radius must be in [0, 8]");
+  if (int rc = require_device()) return rc;
+  NmsArgs a{};
+  a.scores_in = scores; a.B = batch; a.H = h; a.W = w; a.radius = radius; a.scores_out = out;
+  launch_nms_tile(1, a, static_cast<hipStream_t>(stream));
+  SSHIP_HIP_CHECK(hipGetLastError());
+  return SSHIP_OK;
+}
+extern "C" int sship_select_topk(const float* scores, int score_h, int score_w, int input_h, int input_w, double thr,
+                                 int border, int max_kp, int desc_h, int desc_w, float* kp_xys, int* cell_h,
+                                 int* cell_w, int* n_dev, int* n_cand_dev, void* stream) {
+  if (!scores || !kp_xys || !cell_h || !cell_w || !n_dev || score_h <= 0 || score_w <= 0)
+    return fail(SSHIP_ERR_INVALID, "select_topk: bad arguments");
+  if (max_kp <= 0 || max_kp > kMaxKp) return fail(SSHIP_ERR_INVALID, "select_topk: max_kp must be in [1, 4096]");
+  if (int rc = require_device()) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int cap = score_h * score_w;
+  DevBuf cand, cnt;
+  SSHIP_HIP_CHECK(cand.ensure((size_t)cap * 8));
+  SSHIP_HIP_CHECK(cnt.ensure(4));
+  SSHIP_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, s));
+  launch_threshold_scan(scores, score_h, score_w, threshold_as_float(thr), border, cand.as<unsigned long long>(),
+                        cnt.as<int>(), cap, s);
+  TopkArgs t{};
+  t.cand = cand.as<unsigned long long>(); t.cand_count = cnt.as<int>(); t.cap = cap; t.max_kp = max_kp;
+  t.score_w = score_w;
+  t.scale_x = static_cast<float>(input_w) / score_w;  // SuperPoint.cc:707-708
+  t.scale_y = static_cast<float>(input_h) / score_h;
+  t.desc_h = desc_h; t.desc_w = desc_w; t.kp_xys = kp_xys; t.cell_h = cell_h; t.cell_w = cell_w; t.n_out = n_dev;
+  t.n_cand_out = n_cand_dev;
+  launch_topk(t, 1, s);
+  SSHIP_HIP_CHECK(hipGetLastError());
+  SSHIP_HIP_CHECK(hipStreamSynchronize(s));  // scratch buffers die with this scope
+  return SSHIP_OK;
+}
+
+// ====================================================================================================
+// SuperPoint
+// ====================================================================================================
+struct sship_sp {
+  sship_sp_config cfg{};
+  hipStream_t stream = nullptr;
+  float* w1a = nullptr;  // [9][64] tap-major fp32 (fp16-rounded values)
+  float* b1a = nullptr;
+  ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, cPa, cPb, cDa, cDb;
+  sship_pool* pool = nullptr;
+  // activations (channels-last fp16), sized for (B, H, W)
+  int wsB = 0, wsH = 0, wsW = 0;
+  DevBuf img, a1a, a1b, a2a, a2b, a3a, a3b, a4a, a4b, aPa, aDa, draw, logits, cand, cand_count;
+  DevBuf kp, cell_h, cell_w, n_dev, desc_stage, gray_in;
+  PinBuf h_kp, h_n, h_img;
+  int cap = 0;
+  float thr_f = 0.f;
+};
+
+static void sp_shapes(int H, int W, int& H2, int& W2, int& H4, int& W4, int& Hc, int& Wc) {
+  H2 = H / 2; W2 = W / 2; H4 = H2 / 2; W4 = W2 / 2; Hc = H4 / 2; Wc = W4 / 2;  // MaxPool2d(2,2) floors
+}
+
+static int sp_ensure(sship_sp* sp, int B, int H, int W) {
+  if (B <= sp->wsB && H == sp->wsH && W == sp->wsW) return SSHIP_OK;
+  int H2, W2, H4, W4, Hc, Wc;
+  sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
+  if (Hc < 1 || Wc < 1) return fail(SSHIP_ERR_INVALID, "image too small for SuperPoint (needs >= 8x8)");
+  const size_t px1 = (size_t)B * H * W, px2 = (size_t)B * H2 * W2, px4 = (size_t)B * H4 * W4, pxc = (size_t)B * Hc * Wc;
+  const int mk = sp->cfg.max_keypoints;
+  SSHIP_HIP_CHECK(sp->img.ensure(px1));
+  SSHIP_HIP_CHECK(sp->gray_in.ensure(px1 * 3));
+  SSHIP_HIP_CHECK(sp->a1a.ensure(px1 * 64 * 2));
+  SSHIP_HIP_CHECK(sp->a1b.ensure(px2 * 64 * 2));
+  SSHIP_HIP_CHECK(sp->a2a.ensure(px2 * 64 * 2));
+  SSHIP_HIP_CHECK(sp->a2b.ensure(px4 * 64 * 2));
+  SSHIP_HIP_CHECK(sp->a3a.ensure(px4 * 128 * 2));
+  SSHIP_HIP_CHECK(sp->a3b.ensure(pxc * 128 * 2));
+  SSHIP_HIP_CHECK(sp->a4a.ensure(pxc * 128 * 2));
+  SSHIP_HIP_CHECK(sp->a4b.ensure(pxc * 128 * 2));
+  SSHIP_HIP_CHECK(sp->aPa.ensure(pxc * 256 * 2));
+  SSHIP_HIP_CHECK(sp->aDa.ensure(pxc * 256 * 2));
+  SSHIP_HIP_CHECK(sp->draw.ensure(pxc * 256 * 2));
+  SSHIP_HIP_CHECK(sp->logits.ensure(pxc * kLogitStride * 4));
+  sp->cap = Hc * 8 * Wc * 8;
+  SSHIP_HIP_CHECK(sp->cand.ensure((size_t)B * sp->cap * 8));
+  SSHIP_HIP_CHECK(sp->cand_count.ensure((size_t)B * 4));
+  SSHIP_HIP_CHECK(sp->kp.ensure((size_t)B * mk * 3 * 4));
+  SSHIP_HIP_CHECK(sp->cell_h.ensure((size_t)B * mk * 4));
+  SSHIP_HIP_CHECK(sp->cell_w.ensure((size_t)B * mk * 4));
+  SSHIP_HIP_CHECK(sp->n_dev.ensure((size_t)B * 4));
+  SSHIP_HIP_CHECK(sp->h_kp.ensure((size_t)B * mk * 3 * 4));
+  SSHIP_HIP_CHECK(sp->h_n.ensure((size_t)B * 4));
+  SSHIP_HIP_CHECK(sp->h_img.ensure(px1 * 3));
+  sp->wsB = B; sp->wsH = H; sp->wsW = W;
+  return SSHIP_OK;
+}
+
+// encoder + both heads up to (logits, raw descriptor grid).  utils/convert_superpoint_to_onnx.py:51-64,77,88.
+static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hipStream_t s) {
+  int H2, W2, H4, W4, Hc, Wc;
+  sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
+  launch_conv1a(imgs, sp->w1a, sp->b1a, sp->a1a.as<_Float16>(), B, H, W, s);
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->c1b, sp->a1a.as<_Float16>(), sp->a1b.as<_Float16>(), B, H, W, true, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->c4a, sp->a3b.as<_Float16>(), sp->a4a.as<_Float16>(), B, Hc, Wc, false, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->c4b, sp->a4a.as<_Float16>(), sp->a4b.as<_Float16>(), B, Hc, Wc, false, true, s));
+  g_timer.mark("sp_encoder", s);
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, true, s));
+  SSHIP_HIP_CHECK(sp_conv1x1_f32(sp->cPb, sp->aPa.as<_Float16>(), sp->logits.as<float>(), kLogitStride, B, Hc, Wc, s));
+  SSHIP_HIP_CHECK(sp_conv3x3(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, true, s));
+  SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
+  g_timer.mark("sp_heads", s);
+  return SSHIP_OK;
+}
+
+// heatmap softmax + NMS + threshold -> candidates -> top-k keypoints/cells (all on device).
+static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float* kp_out, int* n_out, hipStream_t s) {
+  int H2, W2, H4, W4, Hc, Wc;
+  sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
+  SSHIP_HIP_CHECK(hipMemsetAsync(sp->cand_count.p, 0, (size_t)B * 4, s));
+  NmsArgs a{};
+  a.logits = sp->logits.as<float>(); a.ls = kLogitStride; a.B = B; a.H = Hc * 8; a.W = Wc * 8;
+  a.radius = sp->cfg.nms_radius; a.thr_f = sp->thr_f; a.border = sp->cfg.remove_borders;
+  a.cand = sp->cand.as<unsigned long long>(); a.cand_count = sp->cand_count.as<int>(); a.cap = sp->cap;
+  a.scores_out = scores_out;
+  launch_nms_tile(0, a, s);
+  TopkArgs t{};
+  t.cand = a.cand; t.cand_count = a.cand_count; t.cap = sp->cap; t.max_kp = sp->cfg.max_keypoints;
+  t.score_w = Wc * 8;
+  t.scale_x = static_cast<float>(W) / (Wc * 8);
+  t.scale_y = static_cast<float>(H) / (Hc * 8);
+  t.desc_h = Hc; t.desc_w = Wc; t.kp_xys = kp_out; t.cell_h = sp->cell_h.as<int>(); t.cell_w = sp->cell_w.as<int>();
+  t.n_out = n_out; t.n_cand_out = nullptr;
+  launch_topk(t, B, s);
+  SSHIP_HIP_CHECK(hipGetLastError());
+  g_timer.mark("sp_select", s);
+  return SSHIP_OK;
+}
+
+extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
+  if (!cfg || !out || !cfg->weights_path) return fail(SSHIP_ERR_INVALID, "sp_create: null argument");
+  if (cfg->max_keypoints <= 0 || cfg->max_keypoints > kMaxKp) return fail(SSHIP_ERR_INVALID, "sp_create: max_keypoints must be in [1, 4096]");
+  if (cfg->nms_radius < 0 || cfg->nms_radius > 8) return fail(SSHIP_ERR_INVALID, "sp_create: nms_radius must be in [0, 8]");
+  if (int rc = require_device()) return rc;
+  StateDict sd; std::string err;
+  if (!load_safetensors(cfg->weights_path, sd, err)) return fail(SSHIP_ERR_IO, err);
+  std::unique_ptr<sship_sp> sp(new sship_sp());
+  sp->cfg = *cfg;
+  if (sp->cfg.pool_slots <= 0) sp->cfg.pool_slots = 8;
+  if (sp->cfg.max_batch <= 0) sp->cfg.max_batch = 2;
+  sp->cfg.weights_path = nullptr;
+  sp->thr_f = threshold_as_float(cfg->keypoint_threshold);
+  struct L { const char* name; int cout, cin, ks, ct; ConvW* dst; };
+  const L layers[] = {{"conv1b", 64, 64, 3, 64, &sp->c1b}, {"conv2a", 64, 64, 3, 64, &sp->c2a},
+                      {"conv2b", 64, 64, 3, 64, &sp->c2b}, {"conv3a", 128, 64, 3, 64, &sp->c3a},
+                      {"conv3b", 128, 128, 3, 64, &sp->c3b}, {"conv4a", 128, 128, 3, 64, &sp->c4a},
+                      {"conv4b", 128, 128, 3, 64, &sp->c4b}, {"convPa", 256, 128, 3, 64, &sp->cPa},
+                      {"convPb", 65, 256, 1, 128, &sp->cPb}, {"convDa", 256, 128, 3, 64, &sp->cDa},
+                      {"convDb", 256, 256, 1, 128, &sp->cDb}};
+  for (const L& l : layers) {
+    const Tensor* w = find_tensor(sd, std::string(l.name) + ".weight", {l.cout, l.cin, l.ks, l.ks}, err);
+    const Tensor* b = w ? find_tensor(sd, std::string(l.name) + ".bias", {l.cout}, err) : nullptr;
+    if (!w || !b) return fail(SSHIP_ERR_IO, err);
+    if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, l.ks, l.ct, *l.dst)) return rc;
+  }
+  {
+    const Tensor* w = find_tensor(sd, "conv1a.weight", {64, 1, 3, 3}, err);
+    const Tensor* b = w ? find_tensor(sd, "conv1a.bias", {64}, err) : nullptr;
+    if (!w || !b) return fail(SSHIP_ERR_IO, err);
+    std::vector<float> wt(576);
+    for (int co = 0; co < 64; ++co)
+      for (int t = 0; t < 9; ++t) wt[t * 64 + co] = (float)(_Float16)w->data[co * 9 + t];  // fp16 engine weights
+    if (int rc = upload_floats(wt.data(), 576, &sp->w1a)) return rc;
+    if (int rc = upload_floats(b->data.data(), 64, &sp->b1a)) return rc;
+  }
+  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
+  if (int rc = sship_pool_create(sp->cfg.pool_slots, sp->cfg.max_keypoints, SSHIP_DESC_DIM, &sp->pool)) return rc;
+  *out = sp.release();
+  return SSHIP_OK;
+}
+extern "C" void sship_sp_destroy(sship_sp* sp) {
+  if (!sp) return;
+  (void)hipDeviceSynchronize();
+  for (ConvW* c : {&sp->c1b, &sp->c2a, &sp->c2b, &sp->c3a, &sp->c3b, &sp->c4a, &sp->c4b, &sp->cPa, &sp->cPb, &sp->cDa, &sp->cDb})
+    free_conv(*c);
+  if (sp->w1a) (void)hipFree(sp->w1a);
+  if (sp->b1a) (void)hipFree(sp->b1a);
+  if (sp->pool) sship_pool_destroy(sp->pool);
+  if (sp->stream) (void)hipStreamDestroy(sp->stream);
+  delete sp;
+}
+extern "C" sship_pool* sship_sp_pool(sship_sp* sp) { return sp ? sp->pool : nullptr; }
+extern "C" int sship_sp_max_keypoints(const sship_sp* sp) { return sp ? sp->cfg.max_keypoints : 0; }
+
+extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, int batch, int h, int w, void* desc_out,
+                                             float* kp_out, int* n_out, void* stream) {
+  if (!sp || !imgs || !desc_out || !kp_out || !n_out || batch <= 0) return fail(SSHIP_ERR_INVALID, "sp_extract_batch_device: bad arguments");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
+  if (int rc = sp_ensure(sp, batch, h, w)) return rc;
+  g_timer.begin(s);
+  if (int rc = sp_network(sp, imgs, batch, h, w, s)) return rc;
+  if (int rc = sp_select(sp, batch, h, w, nullptr, kp_out, n_out, s)) return rc;
+  int H2, W2, H4, W4, Hc, Wc;
+  sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
+  launch_gather_hwc(true, sp->draw.as<_Float16>(), 256, Hc, Wc, (size_t)Hc * Wc * 256, sp->cell_h.as<int>(),
+                    sp->cell_w.as<int>(), n_out, 0, sp->cfg.max_keypoints, batch, static_cast<_Float16*>(desc_out), s);
+  SSHIP_HIP_CHECK(hipGetLastError());
+  g_timer.mark("sp_gather", s);
+  return SSHIP_OK;
+}
+
+extern "C" int sship_sp_dense(sship_sp* sp, const uint8_t* imgs, int batch, int h, int w, float* scores, void* desc_grid,
+                              float* logits, void* stream) {
+  if (!sp || !imgs || batch <= 0) return fail(SSHIP_ERR_INVALID, "sp_dense: bad arguments");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
+  if (int rc = sp_ensure(sp, batch, h, w)) return rc;
+  if (int rc = sp_network(sp, imgs, batch, h, w, s)) return rc;
+  int H2, W2, H4, W4, Hc, Wc;
+  sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
+  if (scores) {
+    NmsArgs a{};
+    a.logits = sp->logits.as<float>(); a.ls = kLogitStride; a.B = batch; a.H = Hc * 8; a.W = Wc * 8;
+    a.radius = sp->cfg.nms_radius; a.scores_out = scores;
+    launch_nms_tile(0, a, s);
+  }
+  if (desc_grid) launch_desc_dense_chw(sp->draw.as<_Float16>(), Hc * Wc, batch, static_cast<_Float16*>(desc_grid), s);
+  if (logits) launch_logits_chw(sp->logits.as<float>(), kLogitStride, Hc * Wc, batch, logits, s);
+  SSHIP_HIP_CHECK(hipGetLastError());
+  return SSHIP_OK;
+}
+
+// host-image front: upload (pinned) -> gray -> batch path into pool slots -> D2H keypoints.
+static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int h, int w, int stride, int channels,
+                           sship_features* const* outs) {
+  if (channels != 1 && channels != 3) return fail(SSHIP_ERR_INVALID, "image must have 1 or 3 channels");
+  if (h <= 0 || w <= 0 || stride < w * channels) return fail(SSHIP_ERR_INVALID, "bad image geometry");
+  if (int rc = sp_ensure(sp, B, h, w)) return rc;
+  hipStream_t s = sp->stream;
+  const size_t row = (size_t)w * channels, img_bytes = row * h;
+  uint8_t* hp = sp->h_img.as<uint8_t>();
+  for (int b = 0; b < B; ++b)
+    for (int y = 0; y < h; ++y) memcpy(hp + b * img_bytes + y * row, imgs[b] + (size_t)y * stride, row);
+  const uint8_t* gray = sp->img.as<uint8_t>();
+  if (channels == 1) {
+    SSHIP_HIP_CHECK(hipMemcpyAsync(sp->img.p, hp, img_bytes * B, hipMemcpyHostToDevice, s));
+  } else {
+    SSHIP_HIP_CHECK(hipMemcpyAsync(sp->gray_in.p, hp, img_bytes * B, hipMemcpyHostToDevice, s));
+    launch_bgr2gray(sp->gray_in.as<uint8_t>(), B * h * w, sp->img.as<uint8_t>(), s);
+  }
+  g_timer.begin(s);
+  if (int rc = sp_network(sp, gray, B, h, w, s)) return rc;
+  if (int rc = sp_select(sp, B, h, w, nullptr, sp->kp.as<float>(), sp->n_dev.as<int>(), s)) return rc;
+  int H2, W2, H4, W4, Hc, Wc;
+  sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
+  const int mk = sp->cfg.max_keypoints;
+  int rc_pool = SSHIP_OK;
+  for (int b = 0; b < B; ++b) {
+    outs[b]->n = 0; outs[b]->desc_dev = nullptr;
+    outs[b]->slot = sship_pool_acquire(sp->pool);  // pool_->make(n), SuperPoint.cc:721
+    if (outs[b]->slot < 0) { rc_pool = SSHIP_ERR_POOL_EXHAUSTED; continue; }
+    launch_gather_hwc(true, sp->draw.as<_Float16>() + (size_t)b * Hc * Wc * 256, 256, Hc, Wc, 0,
+                      sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
+                      sp->n_dev.as<int>() + b, 0, mk, 1,
+                      static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), s);
+  }
+  g_timer.mark("sp_gather", s);
+  SSHIP_HIP_CHECK(hipMemcpyAsync(sp->h_kp.p, sp->kp.p, (size_t)B * mk * 12, hipMemcpyDeviceToHost, s));
+  SSHIP_HIP_CHECK(hipMemcpyAsync(sp->h_n.p, sp->n_dev.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  SSHIP_HIP_CHECK(hipStreamSynchronize(s));
+  for (int b = 0; b < B; ++b) {
+    const int n = sp->h_n.as<int>()[b];
+    outs[b]->n = n;
+    if (outs[b]->kp_xys) memcpy(outs[b]->kp_xys, sp->h_kp.as<float>() + (size_t)b * mk * 3, (size_t)n * 12);
+    if (outs[b]->slot >= 0) {
+      if (n == 0) { sship_pool_release(sp->pool, outs[b]->slot); outs[b]->slot = -1; }  // empty handle, SuperPoint.cc:722-723
+      else outs[b]->desc_dev = sship_pool_slot_ptr(sp->pool, outs[b]->slot);
+    }
+  }
+  if (rc_pool) return fail(rc_pool, "SuperPoint: descriptor pool exhausted (no free slot)");
+  return SSHIP_OK;
+}
+
+extern "C" int sship_sp_extract(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels,
+                                sship_features* out) {
+  if (!sp || !img || !out) return fail(SSHIP_ERR_INVALID, "sp_extract: null argument");
+  const uint8_t* imgs[1] = {img};
+  sship_features* outs[1] = {out};
+  return sp_extract_host(sp, imgs, 1, h, w, stride, channels, outs);
+}
+extern "C" int sship_sp_extract_stereo(sship_sp* sp, const uint8_t* left, const uint8_t* right, int h, int w, int stride,
+                                       int channels, sship_features* out_left, sship_features* out_right) {
+  if (!sp || !left || !right || !out_left || !out_right) return fail(SSHIP_ERR_INVALID, "sp_extract_stereo: null argument");
+  const uint8_t* imgs[2] = {left, right};
+  sship_features* outs[2] = {out_left, out_right};
+  return sp_extract_host(sp, imgs, 2, h, w, stride, channels, outs);
+}
+extern "C" int sship_desc_to_host(const void* desc_dev, int count, int dim, float* out) {
+  if (count <= 0 || !desc_dev) return SSHIP_OK;  // empty handle -> empty Mat (LightGlue.cc:461-462)
+  if (!out || dim <= 0) return fail(SSHIP_ERR_INVALID, "desc_to_host: bad arguments");
+  const size_t n = (size_t)count * dim;
+  std::vector<uint16_t> tmp(n);
+  SSHIP_HIP_CHECK(hipMemcpy(tmp.data(), desc_dev, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) out[i] = half_bits_to_float(tmp[i]);
+  return SSHIP_OK;
+}
+extern "C" int sship_sp_infer_host(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels, float* kp_xys,
+                                   float* desc_f32, int* n) {
+  if (!sp || !img || !kp_xys || !desc_f32 || !n) return fail(SSHIP_ERR_INVALID, "sp_infer_host: null argument");
+  sship_features f{};
+  f.kp_xys = kp_xys;
+  if (int rc = sship_sp_extract(sp, img, h, w, stride, channels, &f)) return rc;
+  *n = f.n;
+  int rc = SSHIP_OK;
+  if (f.n > 0) rc = sship_desc_to_host(f.desc_dev, f.n, SSHIP_DESC_DIM, desc_f32);
+  if (f.slot >= 0) sship_pool_release(sp->pool, f.slot);
+  return rc;
+}
+
+// ====================================================================================================
+// LightGlue
+// ====================================================================================================
+constexpr int kLgLayers = 9;
+struct sship_lg_weights {
+  std::mutex mu;
+  int refs = 1;
+  ConvW qkv[kLgLayers], outp[kLgLayers], ffn0_s[kLgLayers], ffn3_s[kLgLayers];
+  ConvW cqkv[kLgLayers], to_out[kLgLayers], ffn0_c[kLgLayers], ffn3_c[kLgLayers];
+  float *ln_g_s[kLgLayers] = {}, *ln_b_s[kLgLayers] = {}, *ln_g_c[kLgLayers] = {}, *ln_b_c[kLgLayers] = {};
+  ConvW final_proj;
+  float* match_w = nullptr;
+  float match_b = 0.f;
+  float* wr = nullptr;
+};
+static void lg_weights_free(sship_lg_weights* w) {
+  for (int i = 0; i < kLgLayers; ++i) {
+    for (ConvW* c : {&w->qkv[i], &w->outp[i], &w->ffn0_s[i], &w->ffn3_s[i], &w->cqkv[i], &w->to_out[i], &w->ffn0_c[i], &w->ffn3_c[i]})
+      free_conv(*c);
+    for (float* p : {w->ln_g_s[i], w->ln_b_s[i], w->ln_g_c[i], w->ln_b_c[i]}) if (p) (void)hipFree(p);
+  }
+  free_conv(w->final_proj);
+  if (w->match_w) (void)hipFree(w->match_w);
+  if (w->wr) (void)hipFree(w->wr);
+  delete w;
+}
+
+extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
+  if (!path || !out) return fail(SSHIP_ERR_INVALID, "lg_weights_load: null argument");
+  if (int rc = require_device()) return rc;
+  StateDict sd; std::string err;
+  if (!load_safetensors(path, sd, err)) return fail(SSHIP_ERR_IO, err);
+  sship_lg_weights* w = new sship_lg_weights();
+  auto bail = [&](int rc, const std::string& m) { lg_weights_free(w); return fail(rc, m); };
+  auto lin = [&](const std::string& name, int cout, int cin, ConvW& dst, const std::vector<int>* map = nullptr,
+                 const std::vector<float>* scale = nullptr) -> int {
+    const Tensor* wt = find_tensor(sd, name + ".weight", {cout, cin}, err);
+    const Tensor* bs = wt ? find_tensor(sd, name + ".bias", {cout}, err) : nullptr;
+    if (!wt || !bs) return SSHIP_ERR_IO;
+    return upload_conv(wt->data.data(), bs->data.data(), cout, cin, 1, 128, dst, map, scale);
+  };
+  auto vec = [&](const std::string& name, int n, float** dst) -> int {
+    const Tensor* t = find_tensor(sd, name, {n}, err);
+    if (!t) return SSHIP_ERR_IO;
+    return upload_floats(t->data.data(), n, dst);
+  };
+  const float kLog2e = 1.4426950408889634f;
+  // SelfBlock Wqkv: unflatten(-1, (4, 64, 3)) -> original row f = h*192 + d*3 + c ; new row R = c*256 + h*64 + d.
+  std::vector<int> qkv_map(768);
+  std::vector<float> qkv_scale(768, 1.f);
+  for (int c = 0; c < 3; ++c)
+    for (int h = 0; h < 4; ++h)
+      for (int d = 0; d < 64; ++d) {
+        const int R = c * 256 + h * 64 + d;
+        qkv_map[R] = h * 192 + d * 3 + c;
+        if (c == 0) qkv_scale[R] = 0.125f * kLog2e;  // softmax(q k^T / sqrt(64)) evaluated with exp2
+      }
+  // CrossBlock: both qk sides are scaled by 64^-0.25; sqrt(log2 e) on each side turns exp into exp2.
+  std::vector<float> cq_scale(256, powf(64.f, -0.25f) * sqrtf(kLog2e));
+  std::vector<float> fp_scale(256, powf(256.f, -0.25f));  // mdesc = final_proj(x) / d^0.25
+  for (int i = 0; i < kLgLayers; ++i) {
+    const std::string ps = "transformers." + std::to_string(i) + ".self_attn.";
+    const std::string pc = "transformers." + std::to_string(i) + ".cross_attn.";
+    int rc = 0;
+    if ((rc = lin(ps + "Wqkv", 768, 256, w->qkv[i], &qkv_map, &qkv_scale))) return bail(rc, err);
+    if ((rc = lin(ps + "out_proj", 256, 256, w->outp[i]))) return bail(rc, err);
+    if ((rc = lin(ps + "ffn.0", 512, 512, w->ffn0_s[i]))) return bail(rc, err);
+    if ((rc = lin(ps + "ffn.3", 256, 512, w->ffn3_s[i]))) return bail(rc, err);
+    if ((rc = vec(ps + "ffn.1.weight", 512, &w->ln_g_s[i]))) return bail(rc, err);
+    if ((rc = vec(ps + "ffn.1.bias", 512, &w->ln_b_s[i]))) return bail(rc, err);
+    // fused [to_qk ; to_v] -> one 512-row GEMM
+    const Tensor* wqk = find_tensor(sd, pc + "to_qk.weight", {256, 256}, err);
+    const Tensor* bqk = wqk ? find_tensor(sd, pc + "to_qk.bias", {256}, err) : nullptr;
+    const Tensor* wv = bqk ? find_tensor(sd, pc + "to_v.weight", {256, 256}, err) : nullptr;
+    const Tensor* bv = wv ? find_tensor(sd, pc + "to_v.bias", {256}, err) : nullptr;
+    if (!bv) return bail(SSHIP_ERR_IO, err);
+    std::vector<float> wcat(512 * 256), bcat(512), scat(512, 1.f);
+    memcpy(wcat.data(), wqk->data.data(), 256 * 256 * 4);
+    memcpy(wcat.data() + 256 * 256, wv->data.data(), 256 * 256 * 4);
+    memcpy(bcat.data(), bqk->data.data(), 256 * 4);
+    memcpy(bcat.data() + 256, bv->data.data(), 256 * 4);
+    for (int r = 0; r < 256; ++r) scat[r] = cq_scale[r];
+    if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 128, w->cqkv[i], nullptr, &scat))) return bail(rc, g_err);
+    if ((rc = lin(pc + "to_out", 256, 256, w->to_out[i]))) return bail(rc, err);
+    if ((rc = lin(pc + "ffn.0", 512, 512, w->ffn0_c[i]))) return bail(rc, err);
+    if ((rc = lin(pc + "ffn.3", 256, 512, w->ffn3_c[i]))) return bail(rc, err);
+    if ((rc = vec(pc + "ffn.1.weight", 512, &w->ln_g_c[i]))) return bail(rc, err);
+    if ((rc = vec(pc + "ffn.1.bias", 512, &w->ln_b_c[i]))) return bail(rc, err);
+  }
+  {
+    // depth_confidence = -1 -> only log_assignment[n_layers - 1] is evaluated (convert_lightglue_to_onnx.py:71-74)
+    const std::string pa = "log_assignment." + std::to_string(kLgLayers - 1) + ".";
+    int rc = 0;
+    if ((rc = lin(pa + "final_proj", 256, 256, w->final_proj, nullptr, &fp_scale))) return bail(rc, err);
+    const Tensor* mw = find_tensor(sd, pa + "matchability.weight", {1, 256}, err);
+    const Tensor* mb = mw ? find_tensor(sd, pa + "matchability.bias", {1}, err) : nullptr;
+    if (!mb) return bail(SSHIP_ERR_IO, err);
+    if ((rc = upload_floats(mw->data.data(), 256, &w->match_w))) return bail(rc, g_err);
+    w->match_b = mb->data[0];
+    const Tensor* wr = find_tensor(sd, "posenc.Wr.weight", {32, 2}, err);
+    if (!wr) return bail(SSHIP_ERR_IO, err);
+    if ((rc = upload_floats(wr->data.data(), 64, &w->wr))) return bail(rc, g_err);
+  }
+  *out = w;
+  return SSHIP_OK;
+}
+extern "C" void sship_lg_weights_retain(sship_lg_weights* w) {
+  if (!w) return;
+  std::lock_guard<std::mutex> g(w->mu);
+  ++w->refs;
+}
+extern "C" void sship_lg_weights_release(sship_lg_weights* w) {
+  if (!w) return;
+  bool last;
+  { std::lock_guard<std::mutex> g(w->mu); last = (--w->refs == 0); }
+  if (last) lg_weights_free(w);
+}
+
+struct sship_lg {
+  sship_lg_weights* w = nullptr;
+  int image_w = 0, image_h = 0, max_kp = 0, max_pairs = 0, NP = 0;
+  hipStream_t stream = nullptr;
+  DevBuf x, rope, q, k, vt, ctx, msg, h1, md, logsig, sim, ws;
+  DevBuf kp_stage, desc_stage, lens, m0, ms0;
+  PinBuf h_kp, h_lens, h_m0, h_ms0, h_desc;
+};
+
+extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, int max_kp, int max_pairs, sship_lg** out) {
+  if (!w || !out || image_w <= 0 || image_h <= 0) return fail(SSHIP_ERR_INVALID, "lg_create: bad arguments");
+  if (max_kp <= 0 || max_kp > kMaxKp) return fail(SSHIP_ERR_INVALID, "lg_create: max_keypoints must be in [1, 4096]");
+  if (max_pairs <= 0) max_pairs = 1;
+  if (int rc = require_device()) return rc;
+  std::unique_ptr<sship_lg> lg(new sship_lg());
+  lg->image_w = image_w; lg->image_h = image_h; lg->max_kp = max_kp; lg->max_pairs = max_pairs;
+  lg->NP = (max_kp + 127) / 128 * 128;
+  const size_t S = 2 * (size_t)max_pairs, T = S * lg->NP, NP = lg->NP;
+  SSHIP_HIP_CHECK(lg->x.ensure(T * 256 * 2));
+  SSHIP_HIP_CHECK(lg->rope.ensure(T * 64 * 4));
+  SSHIP_HIP_CHECK(lg->q.ensure(T * 256 * 2));
+  SSHIP_HIP_CHECK(lg->k.ensure(T * 256 * 2));
+  SSHIP_HIP_CHECK(lg->vt.ensure(T * 256 * 2));
+  SSHIP_HIP_CHECK(lg->ctx.ensure(T * 256 * 2));
+  SSHIP_HIP_CHECK(lg->msg.ensure(T * 256 * 2));
+  SSHIP_HIP_CHECK(lg->h1.ensure(T * 512 * 2));
+  SSHIP_HIP_CHECK(lg->md.ensure(T * 256 * 2));
+  SSHIP_HIP_CHECK(lg->logsig.ensure(T * 4));
+  SSHIP_HIP_CHECK(lg->sim.ensure((size_t)max_pairs * NP * NP * 4));
+  SSHIP_HIP_CHECK(lg->ws.ensure((size_t)max_pairs * 5 * NP * 4));
+  SSHIP_HIP_CHECK(lg->kp_stage.ensure(S * max_kp * 3 * 4));
+  SSHIP_HIP_CHECK(lg->desc_stage.ensure(S * max_kp * 256 * 2));
+  SSHIP_HIP_CHECK(lg->lens.ensure(S * 4));
+  SSHIP_HIP_CHECK(lg->m0.ensure((size_t)max_pairs * max_kp * 4));
+  SSHIP_HIP_CHECK(lg->ms0.ensure((size_t)max_pairs * max_kp * 4));
+  SSHIP_HIP_CHECK(lg->h_kp.ensure(2 * (size_t)max_kp * 3 * 4));
+  SSHIP_HIP_CHECK(lg->h_lens.ensure(2 * 4));
+  SSHIP_HIP_CHECK(lg->h_m0.ensure((size_t)max_kp * 4));
+  SSHIP_HIP_CHECK(lg->h_ms0.ensure((size_t)max_kp * 4));
+  SSHIP_HIP_CHECK(lg->h_desc.ensure(2 * (size_t)max_kp * 256 * 2));
+  // q/k/vt/ctx of padded tokens must stay finite: start from zeros (prep rewrites x every call).
+  SSHIP_HIP_CHECK(hipMemset(lg->q.p, 0, lg->q.bytes));
+  SSHIP_HIP_CHECK(hipMemset(lg->k.p, 0, lg->k.bytes));
+  SSHIP_HIP_CHECK(hipMemset(lg->vt.p, 0, lg->vt.bytes));
+  SSHIP_HIP_CHECK(hipMemset(lg->ctx.p, 0, lg->ctx.bytes));
+  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&lg->stream, hipStreamNonBlocking));
+  sship_lg_weights_retain(w);
+  lg->w = w;
+  *out = lg.release();
+  return SSHIP_OK;
+}
+extern "C" void sship_lg_destroy(sship_lg* lg) {
+  if (!lg) return;
+  (void)hipDeviceSynchronize();
+  if (lg->stream) (void)hipStreamDestroy(lg->stream);
+  sship_lg_weights_release(lg->w);
+  delete lg;
+}
+extern "C" int sship_lg_normalize_keypoints(const sship_lg* lg, const float* kp, int stride, int n, float* out) {
+  if (!lg || !kp || !out || stride < 2) return fail(SSHIP_ERR_INVALID, "lg_normalize_keypoints: bad arguments");
+  const float scale = std::max(lg->image_w, lg->image_h) / 2.0f;  // LightGlue.cc:242-244
+  const float cx = lg->image_w / 2.0f, cy = lg->image_h / 2.0f;
+  for (int i = 0; i < n; ++i) {
+    out[2 * i + 0] = (kp[(size_t)i * stride + 0] - cx) / scale;
+    out[2 * i + 1] = (kp[(size_t)i * stride + 1] - cy) / scale;
+  }
+  return SSHIP_OK;
+}
+
+// The matcher proper: `pairs` problems, everything on the device.  9 x (SelfBlock x2 images, CrossBlock), then
+// log_assignment[8] + filter_matches.
+static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_stride, const int* lens,
+                      const _Float16* desc, size_t desc_seq_stride, int pairs, int32_t* m0, float* ms0, hipStream_t s) {
+  const sship_lg_weights* w = lg->w;
+  LgDims d{2 * pairs, lg->NP};
+  const int T = d.S * d.NP;
+  _Float16 *x = lg->x.as<_Float16>(), *q = lg->q.as<_Float16>(), *k = lg->k.as<_Float16>(), *vt = lg->vt.as<_Float16>();
+  _Float16 *ctx = lg->ctx.as<_Float16>(), *msg = lg->msg.as<_Float16>(), *h1 = lg->h1.as<_Float16>();
+  float* rope = lg->rope.as<float>();
+  launch_lg_prep(kp, kp_stride, kp_seq_stride, lens, desc, desc_seq_stride, w->wr, (float)lg->image_w,
+                 (float)lg->image_h, d, x, rope, s);
+  for (int i = 0; i < kLgLayers; ++i) {
+    // SelfBlock (both images of every pair in one launch)
+    SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[i], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
+    launch_lg_attention(q, k, vt, lens, d, false, ctx, s);
+    SSHIP_HIP_CHECK(lg_linear_f16(w->outp[i], ctx, 256, nullptr, 0, d, msg, 256, s));
+    SSHIP_HIP_CHECK(lg_linear_f16(w->ffn0_s[i], x, 256, msg, 256, d, h1, 512, s));
+    launch_lg_ln_gelu(h1, w->ln_g_s[i], w->ln_b_s[i], T, s);
+    SSHIP_HIP_CHECK(lg_linear_resid(w->ffn3_s[i], h1, 512, d, x, s));
+    // CrossBlock (qk shared by both directions; sequence s attends to s^1)
+    SSHIP_HIP_CHECK(lg_linear_heads(w->cqkv[i], x, d, /*rope_segs=*/0, /*t_seg=*/1, rope, q, k, vt, s));
+    launch_lg_attention(q, q, vt, lens, d, true, ctx, s);
+    SSHIP_HIP_CHECK(lg_linear_f16(w->to_out[i], ctx, 256, nullptr, 0, d, msg, 256, s));
+    SSHIP_HIP_CHECK(lg_linear_f16(w->ffn0_c[i], x, 256, msg, 256, d, h1, 512, s));
+    launch_lg_ln_gelu(h1, w->ln_g_c[i], w->ln_b_c[i], T, s);
+    SSHIP_HIP_CHECK(lg_linear_resid(w->ffn3_c[i], h1, 512, d, x, s));
+  }
+  SSHIP_HIP_CHECK(lg_linear_f16(w->final_proj, x, 256, nullptr, 0, d, lg->md.as<_Float16>(), 256, s));
+  launch_lg_matchability(x, w->match_w, w->match_b, T, lg->logsig.as<float>(), s);
+  launch_lg_sim(lg->md.as<_Float16>(), lens, d, lg->sim.as<float>(), s);
+  launch_lg_assign(lg->sim.as<float>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->max_kp, m0, ms0,
+                   0.1f /* filter_threshold */, s);
+  SSHIP_HIP_CHECK(hipGetLastError());
+  g_timer.mark("lg_match", s);
+  return SSHIP_OK;
+}
+
+extern "C" int sship_lg_match_batch_device(sship_lg* lg, const float* kp, const int* n, const void* desc, int pairs,
+                                           int32_t* m0, float* ms0, void* stream) {
+  if (!lg || !kp || !n || !desc || !m0 || !ms0) return fail(SSHIP_ERR_INVALID, "lg_match_batch_device: null argument");
+  if (pairs <= 0 || pairs > lg->max_pairs) return fail(SSHIP_ERR_INVALID, "lg_match_batch_device: pairs exceeds max_pairs");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lg->stream;
+  return lg_forward(lg, kp, 3, lg->max_kp * 3, n, static_cast<const _Float16*>(desc), (size_t)lg->max_kp * 256, pairs,
+                    m0, ms0, s);
+}
+
+static int lg_match_common(sship_lg* lg, const float* kp0, int st0, int n0, const float* kp1, int st1, int n1,
+                           int32_t* matches0, float* mscores0) {
+  // kpts -> pinned [2, max_kp, 3] (x, y, 0) -> device; descriptors already staged in desc_stage.
+  hipStream_t s = lg->stream;
+  float* hk = lg->h_kp.as<float>();
+  const int mk = lg->max_kp;
+  for (int i = 0; i < n0; ++i) { hk[3 * i] = kp0[(size_t)i * st0]; hk[3 * i + 1] = kp0[(size_t)i * st0 + 1]; hk[3 * i + 2] = 0.f; }
+  for (int i = 0; i < n1; ++i) {
+    hk[(size_t)mk * 3 + 3 * i] = kp1[(size_t)i * st1]; hk[(size_t)mk * 3 + 3 * i + 1] = kp1[(size_t)i * st1 + 1];
+    hk[(size_t)mk * 3 + 3 * i + 2] = 0.f;
+  }
+  lg->h_lens.as<int>()[0] = n0; lg->h_lens.as<int>()[1] = n1;
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->kp_stage.p, hk, 2 * (size_t)mk * 12, hipMemcpyHostToDevice, s));
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->lens.p, lg->h_lens.p, 8, hipMemcpyHostToDevice, s));
+  if (int rc = lg_forward(lg, lg->kp_stage.as<float>(), 3, mk * 3, lg->lens.as<int>(), lg->desc_stage.as<_Float16>(),
+                          (size_t)mk * 256, 1, lg->m0.as<int32_t>(), lg->ms0.as<float>(), s))
+    return rc;
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->h_m0.p, lg->m0.p, (size_t)n0 * 4, hipMemcpyDeviceToHost, s));
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->h_ms0.p, lg->ms0.p, (size_t)n0 * 4, hipMemcpyDeviceToHost, s));
+  SSHIP_HIP_CHECK(hipStreamSynchronize(s));
+  memcpy(matches0, lg->h_m0.p, (size_t)n0 * 4);
+  memcpy(mscores0, lg->h_ms0.p, (size_t)n0 * 4);
+  return SSHIP_OK;
+}
+
+extern "C" int sship_lg_match_device(sship_lg* lg, const float* kp0, int st0, int n0, const void* desc0, const float* kp1,
+                                     int st1, int n1, const void* desc1, int32_t* matches0, float* mscores0) {
+  if (!lg || !kp0 || !kp1 || !desc0 || !desc1 || !matches0 || !mscores0) return fail(SSHIP_ERR_INVALID, "lg_match_device: null argument");
+  if (n0 <= 0 || n1 <= 0) return fail(SSHIP_ERR_INVALID, "lg_match_device: empty keypoint set");  // LightGlue.cc:381-385
+  if (n0 > lg->max_kp || n1 > lg->max_kp || st0 < 2 || st1 < 2) return fail(SSHIP_ERR_INVALID, "lg_match_device: n exceeds max_keypoints");
+  hipStream_t s = lg->stream;
+  // D2D of exactly the slot bytes into the matcher's inputs (LightGlue.cc:425-441)
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->desc_stage.p, desc0, (size_t)n0 * 512, hipMemcpyDeviceToDevice, s));
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->desc_stage.as<_Float16>() + (size_t)lg->max_kp * 256, desc1, (size_t)n1 * 512,
+                                 hipMemcpyDeviceToDevice, s));
+  return lg_match_common(lg, kp0, st0, n0, kp1, st1, n1, matches0, mscores0);
+}
+extern "C" int sship_lg_match_host(sship_lg* lg, const float* kp0, int st0, int n0, const float* desc0, const float* kp1,
+                                   int st1, int n1, const float* desc1, int32_t* matches0, float* mscores0) {
+  if (!lg || !kp0 || !kp1 || !desc0 || !desc1 || !matches0 || !mscores0) return fail(SSHIP_ERR_INVALID, "lg_match_host: null argument");
+  if (n0 <= 0 || n1 <= 0) return fail(SSHIP_ERR_INVALID, "lg_match_host: empty keypoint set");  // LightGlue.cc:294-295
+  if (n0 > lg->max_kp || n1 > lg->max_kp || st0 < 2 || st1 < 2) return fail(SSHIP_ERR_INVALID, "lg_match_host: n exceeds max_keypoints");
+  hipStream_t s = lg->stream;
+  _Float16* hd = lg->h_desc.as<_Float16>();  // store_floats: CV_32F -> engine dtype on the host (LightGlue.cc:227-238)
+  for (size_t i = 0; i < (size_t)n0 * 256; ++i) hd[i] = (_Float16)desc0[i];
+  for (size_t i = 0; i < (size_t)n1 * 256; ++i) hd[(size_t)lg->max_kp * 256 + i] = (_Float16)desc1[i];
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->desc_stage.p, hd, (size_t)n0 * 512, hipMemcpyHostToDevice, s));
+  SSHIP_HIP_CHECK(hipMemcpyAsync(lg->desc_stage.as<_Float16>() + (size_t)lg->max_kp * 256, hd + (size_t)lg->max_kp * 256,
+                                 (size_t)n1 * 512, hipMemcpyHostToDevice, s));
+  return lg_match_common(lg, kp0, st0, n0, kp1, st1, n1, matches0, mscores0);
+}
+extern "C" int sship_filter_matches(const int32_t* matches0, const float* mscores0, int n0, int* q, int* t, float* dist) {
+  if (n0 <= 0) return 0;
+  if (!matches0 || !q || !t || !dist) return -1;
+  int k = 0;
+  for (int i = 0; i < n0; ++i) {  // LightGlue.cc:351-361
+    const int j = matches0[i];
+    if (j < 0) continue;
+    q[k] = i; t[k] = j; dist[k] = 1.0f - (mscores0 ? mscores0[i] : 1.0f);
+    ++k;
+  }
+  return k;
+}
+
+// ====================================================================================================
+// fused front-end step: SuperPoint(batch 2P) + select + gather + LightGlue(P)
+// ====================================================================================================
+extern "C" int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs, int pairs, int h, int w,
+                                           void* desc_out, float* kp_out, int* n_out, int32_t* m0, float* ms0,
+                                           void* stream) {
+  if (!sp || !lg || !imgs || !desc_out || !kp_out || !n_out || !m0 || !ms0) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: null argument");
+  if (pairs <= 0 || pairs > lg->max_pairs) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: pairs exceeds the matcher's max_pairs");
+  if (sp->cfg.max_keypoints != lg->max_kp) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: extractor and matcher disagree on max_keypoints");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
+  if (int rc = sship_sp_extract_batch_device(sp, imgs, 2 * pairs, h, w, desc_out, kp_out, n_out, s)) return rc;
+  return lg_forward(lg, kp_out, 3, lg->max_kp * 3, n_out, static_cast<const _Float16*>(desc_out), (size_t)lg->max_kp * 256,
+                    pairs, m0, ms0, s);
+}

@@ -1,0 +1,58 @@
+// Shared device/host helpers for libsuperslam_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace sship {
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));   // MFMA A/B fragment: 8 f16 (4 VGPRs)
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f16x_t __attribute__((ext_vector_type(16)));   // 32x32 MFMA accumulator
+typedef float f4x_t __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+// Thread-local last error + status plumbing (host side).
+void set_error(const std::string& msg);
+void log_msg(int level, const char* fmt, ...);
+
+#define SSHIP_HIP_CHECK(expr)                                                              \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ::sship::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+      return SSHIP_ERR_HIP;                                                                \
+    }                                                                                      \
+  } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// MFMA 32x32x16 f16: D[32x32] += A[32x16] * B[16x32].
+//   A fragment: lane l holds A[i = l & 31][k = 8*(l >> 5) + e], e = 0..7
+//   B fragment: lane l holds B[k = 8*(l >> 5) + e][j = l & 31]
+//   D: lane l, reg r holds D[row = (r & 3) + 8*(r >> 2) + 4*(l >> 5)][col = l & 31]
+__device__ __forceinline__ f16x_t mfma32(h8_t a, h8_t b, f16x_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ h4_t to_h4(float a, float b, float c, float d) {
+  h4_t v;
+  v[0] = (_Float16)a; v[1] = (_Float16)b; v[2] = (_Float16)c; v[3] = (_Float16)d;
+  return v;
+}
+
+}  // namespace sship

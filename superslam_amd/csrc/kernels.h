@@ -1,0 +1,89 @@
+// Internal kernel launch interface of libsuperslam_hip (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+namespace sship {
+
+constexpr int kMaxKp = 4096;   // upper bound on max_keypoints (top-k sorts in LDS)
+constexpr int kLogitStride = 128;  // detector logits: 65 channels in a 128-wide fp32 row
+
+// ---- sp_kernels.hip ----
+void launch_conv1a(const uint8_t* img, const float* w, const float* bias, _Float16* out, int B, int H, int W,
+                   hipStream_t s);
+struct NmsArgs {
+  const float* logits;   // [B, Hc, Wc, ls] (loader 0)
+  int ls;
+  const float* scores_in;  // [B, H, W] (loader 1)
+  int B, H, W;             // score-map shape
+  int radius;
+  float thr_f;             // smallest float f with (double)f > thr  ->  keep iff s >= thr_f
+  int border;
+  unsigned long long* cand;  // [B, cap] or null
+  int* cand_count;           // [B]
+  int cap;
+  float* scores_out;         // [B, H, W] post-NMS or null
+  float* scores_raw_out;     // [B, H, W] pre-NMS (softmax + depth-to-space) or null
+};
+float threshold_as_float(double thr);
+void launch_nms_tile(int loader, const NmsArgs& a, hipStream_t s);
+
+struct TopkArgs {
+  const unsigned long long* cand;  // [B, cap]
+  const int* cand_count;           // [B]
+  int cap, max_kp;
+  int score_w;                     // W of the score map (key idx = h*W + w)
+  float scale_x, scale_y;          // input_w / score_w, input_h / score_h (float division on the host)
+  int desc_h, desc_w;
+  float* kp_xys;                   // [B, max_kp, 3]
+  int* cell_h;                     // [B, max_kp]
+  int* cell_w;                     // [B, max_kp]
+  int* n_out;                      // [B]
+  int* n_cand_out;                 // [B] or null
+};
+void launch_topk(const TopkArgs& a, int B, hipStream_t s);
+void launch_threshold_scan(const float* scores, int H, int W, float thr_f, int border, unsigned long long* cand,
+                           int* cand_count, int cap, hipStream_t s);
+void launch_gather_hwc(bool raw, const _Float16* grid, int C, int gh, int gw, size_t img_stride, const int* cell_h,
+                       const int* cell_w, const int* n_dev, int n_host, int max_kp, int B, _Float16* out,
+                       hipStream_t s);
+void launch_gather_chw(const _Float16* grid, int C, int gh, int gw, const int* cell_h, const int* cell_w, int n,
+                       _Float16* out, hipStream_t s);
+void launch_desc_dense_chw(const _Float16* raw, int cells_per_img, int B, _Float16* out, hipStream_t s);
+void launch_logits_chw(const float* in, int ls, int cells_per_img, int B, float* out, hipStream_t s);
+void launch_bgr2gray(const uint8_t* in, int n, uint8_t* out, hipStream_t s);
+
+// ---- sp_convs.hip : MFMA implicit-GEMM layers of SuperPoint ----
+struct ConvW {          // one packed conv / linear layer on the device
+  _Float16* w = nullptr;  // packed A-fragment order (igemm.h)
+  float* bias = nullptr;  // [cout_pad]
+  int cin = 0, cout = 0, cout_pad = 0, ks = 1, ct = 64;
+};
+// in: channels-last fp16 [B,H,W,cin]; out: [B,Ho,Wo,cout] fp16 (pool: floor(/2)).
+hipError_t sp_conv3x3(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, bool relu,
+                      hipStream_t s);
+hipError_t sp_conv1x1_f16(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s);
+hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int ostride, int B, int H, int W,
+                          hipStream_t s);
+
+// ---- lg_kernels.hip ----
+struct LgDims {
+  int S;    // sequences (2 * pairs)
+  int NP;   // padded tokens per sequence (multiple of 128)
+};
+void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int* lens, const _Float16* desc,
+                    size_t desc_seq_stride, const float* wr, float img_w, float img_h, LgDims d, _Float16* x,
+                    float* rope, hipStream_t s);
+hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope_segs, int t_seg,
+                           const float* rope, _Float16* q, _Float16* k, _Float16* vt, hipStream_t s);
+hipError_t lg_linear_f16(const ConvW& w, const _Float16* in0, int cs0, const _Float16* in1, int cs1, LgDims d,
+                         _Float16* out, int ostride, hipStream_t s);
+hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d, _Float16* x, hipStream_t s);
+void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,
+                         bool cross, _Float16* ctx, hipStream_t s);
+void launch_lg_ln_gelu(_Float16* h, const float* gamma, const float* beta, int tokens, hipStream_t s);
+void launch_lg_matchability(const _Float16* x, const float* w, float bias, int tokens, float* logsig, hipStream_t s);
+void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s);
+void launch_lg_assign(const float* sim, const float* logsig, const int* lens, LgDims d, float* ws, int max_kp,
+                      int32_t* matches0, float* mscores0, float thr, hipStream_t s);
+
+}  // namespace sship

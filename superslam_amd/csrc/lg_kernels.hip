@@ -1,0 +1,443 @@
+// LightGlue kernels (SURVEY.md 8(a)-LG restates the upstream algorithm; call sites src/LightGlue.cc:313,446).
+// Token streams are channels-last fp16 [S*NP][256]; S = 2*pairs sequences (2p = set 0, 2p+1 = set 1 of pair p),
+// NP = padded tokens per sequence.  Per-sequence valid lengths live in device memory (`lens`) so the whole
+// matcher runs without a host round trip after SuperPoint's on-device top-k.
+#include "igemm.h"
+#include "kernels.h"
+
+namespace sship {
+
+// ---------------------------------------------------------------------------------------------------
+// prep: x <- descriptors (zero rows for padding), rotary table <- posenc(normalised keypoints).
+// reference: keypoint normalisation src/LightGlue.cc:241-251; LearnableFourierPositionalEncoding(2,64,64).
+// rope[token][i] = (cos, sin)(Wr[i,0]*kx + Wr[i,1]*ky), i < 32 (shared by the 4 heads).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lg_prep(const float* __restrict__ kp, int kp_stride, int kp_seq_stride,
+                                                 const int* __restrict__ lens, const _Float16* __restrict__ desc,
+                                                 size_t desc_seq_stride, const float* __restrict__ wr, float img_w,
+                                                 float img_h, int S, int NP, _Float16* __restrict__ x,
+                                                 float* __restrict__ rope) {
+  const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (token >= S * NP) return;
+  const int s = token / NP, n = token % NP;
+  const bool valid = n < lens[s];
+  h4_t v = to_h4(0.f, 0.f, 0.f, 0.f);
+  if (valid) v = *reinterpret_cast<const h4_t*>(desc + (size_t)s * desc_seq_stride + (size_t)n * 256 + lane * 4);
+  *reinterpret_cast<h4_t*>(x + (size_t)token * 256 + lane * 4) = v;
+  if (lane < 32) {
+    float c = 1.f, sn = 0.f;
+    if (valid) {
+      const float* k = kp + (size_t)s * kp_seq_stride + (size_t)n * kp_stride;
+      const float scale = fmaxf(img_w, img_h) / 2.0f;   // std::max(w, h) / 2.0f
+      const float kx = (k[0] - img_w / 2.0f) / scale;   // (pt.x - cx) / scale
+      const float ky = (k[1] - img_h / 2.0f) / scale;
+      const float pr = wr[lane * 2 + 0] * kx + wr[lane * 2 + 1] * ky;
+      c = cosf(pr);
+      sn = sinf(pr);
+    }
+    rope[(size_t)token * 64 + lane * 2 + 0] = c;
+    rope[(size_t)token * 64 + lane * 2 + 1] = sn;
+  }
+}
+void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int* lens, const _Float16* desc,
+                    size_t desc_seq_stride, const float* wr, float img_w, float img_h, LgDims d, _Float16* x,
+                    float* rope, hipStream_t s) {
+  const int tokens = d.S * d.NP;
+  hipLaunchKernelGGL(k_lg_prep, dim3((tokens + 3) / 4), dim3(256), 0, s, kp, kp_stride, kp_seq_stride, lens, desc,
+                     desc_seq_stride, wr, img_w, img_h, d.S, d.NP, x, rope);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// igemm epilogues for the Linear layers.  A "pixel" is a token: token = y*32 + x (the token stream is an
+// image of width 32).  Output rows come in 256-wide segments:
+//   SelfBlock  Wqkv : rows permuted on the host to [q | k | v] x [head][64]  -> rope on q,k, v transposed
+//   CrossBlock      : [to_qk | to_v] fused into one 512-row GEMM            -> no rope, v transposed
+// Softmax scale (and log2 e for exp2) are folded into the q / qk rows on the host.
+// ---------------------------------------------------------------------------------------------------
+struct EpiHeads {
+  template <int MT, int NT>
+  static __device__ __forceinline__ void run(const IgemmArgs& p, f16x_t (&acc)[MT][NT], int b, int yb, int x,
+                                             int cb0, int hh) {
+    const int rope_segs = p.flags & 0xf, t_seg = (p.flags >> 4) & 0xf;
+    const int NP = p.np;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int token = (yb + n) * 32 + x;
+      if (yb + n >= p.H) continue;
+      const int s = token / NP, tn = token - s * NP;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int R0 = cb0 + m * 32 + hh * 4 + g * 8;
+          if (R0 >= p.cout) continue;
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + R0);
+          float v0 = acc[m][n][4 * g + 0] + bv.x, v1 = acc[m][n][4 * g + 1] + bv.y;
+          float v2 = acc[m][n][4 * g + 2] + bv.z, v3 = acc[m][n][4 * g + 3] + bv.w;
+          const int seg = R0 >> 8, hd = (R0 >> 6) & 3, d0 = R0 & 63;
+          if (seg < rope_segs) {
+            // rotate_half on interleaved pairs: out[2i] = x[2i] c_i - x[2i+1] s_i ; out[2i+1] = x[2i+1] c_i + x[2i] s_i
+            const float4 cs = *reinterpret_cast<const float4*>(p.aux + (size_t)token * 64 + d0);  // (c0,s0,c1,s1)
+            const float r0 = v0 * cs.x - v1 * cs.y, r1 = v1 * cs.x + v0 * cs.y;
+            const float r2 = v2 * cs.z - v3 * cs.w, r3 = v3 * cs.z + v2 * cs.w;
+            v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+          }
+          if (seg != t_seg) {
+            _Float16* dst = static_cast<_Float16*>(seg == 0 ? p.out0 : p.out1);
+            *reinterpret_cast<h4_t*>(dst + (((size_t)s * 4 + hd) * NP + tn) * 64 + d0) = to_h4(v0, v1, v2, v3);
+          } else {
+            _Float16* dst = static_cast<_Float16*>(p.out2) + (((size_t)s * 4 + hd) * 64 + d0) * NP + tn;
+            dst[0] = (_Float16)v0; dst[NP] = (_Float16)v1; dst[2 * (size_t)NP] = (_Float16)v2; dst[3 * (size_t)NP] = (_Float16)v3;
+          }
+        }
+    }
+  }
+};
+
+// x[token] += W h + b   (in place on the fp16 residual stream; the add runs in fp32)
+struct EpiResid {
+  template <int MT, int NT>
+  static __device__ __forceinline__ void run(const IgemmArgs& p, f16x_t (&acc)[MT][NT], int b, int yb, int x,
+                                             int cb0, int hh) {
+    _Float16* xs = static_cast<_Float16*>(p.out0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (yb + n >= p.H) continue;
+      const size_t token = (size_t)(yb + n) * 32 + x;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = cb0 + m * 32 + hh * 4 + g * 8;
+          if (c >= p.cout) continue;
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + c);
+          h4_t* px = reinterpret_cast<h4_t*>(xs + token * p.ostride + c);
+          const h4_t o = *px;
+          *px = to_h4((float)o[0] + (acc[m][n][4 * g + 0] + bv.x), (float)o[1] + (acc[m][n][4 * g + 1] + bv.y),
+                      (float)o[2] + (acc[m][n][4 * g + 2] + bv.z), (float)o[3] + (acc[m][n][4 * g + 3] + bv.w));
+        }
+    }
+  }
+};
+
+static IgemmArgs token_args(const ConvW& w, const _Float16* in0, int cs0, const _Float16* in1, int cs1, LgDims d) {
+  IgemmArgs a{};
+  a.in0 = in0; a.in1 = in1 ? in1 : in0; a.cs0 = cs0; a.cs1 = in1 ? cs1 : cs0;
+  a.cin0 = in1 ? cs0 : w.cin;
+  a.wpack = w.w; a.bias = w.bias;
+  a.B = 1; a.H = d.S * d.NP / 32; a.W = 32;
+  a.cout = w.cout; a.np = d.NP;
+  return a;
+}
+
+hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope_segs, int t_seg, const float* rope,
+                           _Float16* q, _Float16* k, _Float16* vt, hipStream_t s) {
+  IgemmArgs a = token_args(w, x, 256, nullptr, 0, d);
+  a.out0 = q; a.out1 = k; a.out2 = vt; a.aux = rope; a.flags = rope_segs | (t_seg << 4);
+  return launch_igemm<1, 256, 128, 8, EpiHeads>(a, w.cout_pad, s);
+}
+hipError_t lg_linear_f16(const ConvW& w, const _Float16* in0, int cs0, const _Float16* in1, int cs1, LgDims d,
+                         _Float16* out, int ostride, hipStream_t s) {
+  IgemmArgs a = token_args(w, in0, cs0, in1, cs1, d);
+  a.out0 = out; a.ostride = ostride;
+  if (w.cin == 256) return launch_igemm<1, 256, 128, 8, EpiF16<false, false>>(a, w.cout_pad, s);
+  return launch_igemm<1, 512, 128, 8, EpiF16<false, false>>(a, w.cout_pad, s);
+}
+hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d, _Float16* x, hipStream_t s) {
+  IgemmArgs a = token_args(w, in, cs, nullptr, 0, d);
+  a.out0 = x; a.ostride = 256;
+  return launch_igemm<1, 512, 128, 8, EpiResid>(a, w.cout_pad, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Flash-style attention, one wave per 32 queries, head_dim 64.  Self (keys = own sequence) and cross
+// (keys = partner sequence s^1: both directions of CrossBlock in one launch).
+// S^T = K Q^T is computed "swapped" so a lane owns ONE query column: the online-softmax statistics are
+// lane-local plus one exchange with lane^32.  The key order inside a 32-key tile is whatever the MFMA
+// C-layout hands out; V^T is fetched with the same permutation, so P never moves between lanes:
+//   reg r of lane (j, hh)  <->  key k0 + (r&3) + 8*(r>>2) + 4*hh
+//   PV K-step kk uses regs 8kk..8kk+7 = keys {16kk + 4hh + e, 16kk + 8 + 4hh + e}, e = 0..3.
+// Scores arrive pre-scaled by log2(e)/sqrt(64) (folded into the projection weights) -> exp2f.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
+                                                      const _Float16* __restrict__ vt, const int* __restrict__ lens,
+                                                      int NP, int cross, _Float16* __restrict__ ctx) {
+  const int s = blockIdx.z, h = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int sk = cross ? (s ^ 1) : s;
+  const int nq = lens[s], nk = lens[sk];
+  if (q0 >= nq) return;
+  const _Float16* Q = q + ((size_t)(s * 4 + h) * NP) * 64;
+  const _Float16* K = k + ((size_t)(sk * 4 + h) * NP) * 64;
+  const _Float16* VT = vt + ((size_t)(sk * 4 + h) * 64) * NP;
+  h8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const h8_t*>(Q + (size_t)(q0 + j) * 64 + ks * 16 + hh * 8);
+  float m = -INFINITY, l = 0.f;
+  f16x_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  for (int k0 = 0; k0 < nk; k0 += 32) {
+    f16x_t st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const h8_t a = *reinterpret_cast<const h8_t*>(K + (size_t)(k0 + j) * 64 + ks * 16 + hh * 8);
+      st = mfma32(a, qf[ks], st);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (key >= nk) st[r] = -INFINITY;
+      tmax = fmaxf(tmax, st[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = exp2f(m - m_new);
+    m = m_new;
+    float ls = 0.f;
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p[r] = exp2f(st[r] - m_new); ls += p[r]; }
+    l = l * alpha + ls;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      h8_t pb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pb[e] = (_Float16)p[8 * kk + e];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const _Float16* vp = VT + (size_t)(mt * 32 + j) * NP + k0 + 16 * kk + 4 * hh;
+        const h4_t lo = *reinterpret_cast<const h4_t*>(vp);
+        const h4_t hi = *reinterpret_cast<const h4_t*>(vp + 8);
+        h8_t a;
+        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+        o[mt] = mfma32(a, pb, o[mt]);
+      }
+    }
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  _Float16* orow = ctx + ((size_t)s * NP + q0 + j) * 256 + h * 64;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = mt * 32 + hh * 4 + g * 8;
+      *reinterpret_cast<h4_t*>(orow + d) =
+          to_h4(o[mt][4 * g + 0] * inv, o[mt][4 * g + 1] * inv, o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv);
+    }
+}
+void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
+                         _Float16* ctx, hipStream_t s) {
+  hipLaunchKernelGGL(k_lg_attention, dim3(d.NP / 128, 4, d.S), dim3(256), 0, s, q, k, vt, lens, d.NP, cross ? 1 : 0,
+                     ctx);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm(512, affine, eps 1e-5) + exact (erf) GELU, in place, one wave per token (8 values per lane).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lg_ln_gelu(_Float16* __restrict__ h, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int tokens) {
+  const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (token >= tokens) return;
+  h8_t* p = reinterpret_cast<h8_t*>(h + (size_t)token * 512 + lane * 8);
+  const h8_t v = *p;
+  float f[8];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { f[e] = (float)v[e]; sum += f[e]; }
+  const float mean = wave_sum(sum) * (1.0f / 512.0f);
+  float sq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { f[e] -= mean; sq += f[e] * f[e]; }
+  const float rstd = rsqrtf(wave_sum(sq) * (1.0f / 512.0f) + 1e-5f);
+  h8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float y = f[e] * rstd * gamma[lane * 8 + e] + beta[lane * 8 + e];
+    o[e] = (_Float16)(0.5f * y * (1.0f + erff(y * 0.70710678118654752f)));
+  }
+  *p = o;
+}
+void launch_lg_ln_gelu(_Float16* h, const float* gamma, const float* beta, int tokens, hipStream_t s) {
+  hipLaunchKernelGGL(k_lg_ln_gelu, dim3((tokens + 3) / 4), dim3(256), 0, s, h, gamma, beta, tokens);
+}
+
+// logsigmoid(matchability(x)) per token.
+__global__ __launch_bounds__(256) void k_lg_matchability(const _Float16* __restrict__ x, const float* __restrict__ w,
+                                                         float bias, int tokens, float* __restrict__ logsig) {
+  const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (token >= tokens) return;
+  const h4_t v = *reinterpret_cast<const h4_t*>(x + (size_t)token * 256 + lane * 4);
+  float d = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d += (float)v[e] * w[lane * 4 + e];
+  const float z = wave_sum(d) + bias;
+  if (lane == 0) logsig[token] = fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
+}
+void launch_lg_matchability(const _Float16* x, const float* w, float bias, int tokens, float* logsig, hipStream_t s) {
+  hipLaunchKernelGGL(k_lg_matchability, dim3((tokens + 3) / 4), dim3(256), 0, s, x, w, bias, tokens, logsig);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Assignment: sim = md0 md1^T (fp32, [pairs][NP][NP]), then the double log-softmax + mutual arg-max filter.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lg_sim(const _Float16* __restrict__ md, const int* __restrict__ lens, int NP,
+                                                float* __restrict__ sim) {
+  const int pair = blockIdx.z;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jl = lane & 31, hh = lane >> 5;
+  const int i0 = blockIdx.y * 32, j0 = (blockIdx.x * 4 + wave) * 32;
+  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  if (i0 >= n0 || j0 >= n1) return;
+  const _Float16* A = md + ((size_t)(2 * pair) * NP + i0 + jl) * 256 + hh * 8;
+  const _Float16* Bm = md + ((size_t)(2 * pair + 1) * NP + j0 + jl) * 256 + hh * 8;
+  f16x_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+    acc = mfma32(*reinterpret_cast<const h8_t*>(A + ks * 16), *reinterpret_cast<const h8_t*>(Bm + ks * 16), acc);
+  float* out = sim + (size_t)pair * NP * NP;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    out[(size_t)i * NP + j0 + jl] = acc[r];
+  }
+}
+void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s) {
+  hipLaunchKernelGGL(k_lg_sim, dim3(d.NP / 128, d.NP / 32, d.S / 2), dim3(256), 0, s, md, lens, d.NP, sim);
+}
+
+// workspace per pair (floats): [0,NP) lse_row, [NP,2NP) lse_col, [2NP,3NP) max0, [3NP,4NP) m0 (int), [4NP,5NP) m1 (int)
+__global__ __launch_bounds__(256) void k_assign_row_lse(const float* __restrict__ sim, const int* __restrict__ lens,
+                                                        int NP, float* __restrict__ ws) {
+  const int pair = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  if (i >= n0) return;
+  const float* row = sim + ((size_t)pair * NP + i) * NP;
+  float m = -INFINITY;
+  for (int j = lane; j < n1; j += 64) m = fmaxf(m, row[j]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int j = lane; j < n1; j += 64) sum += expf(row[j] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) ws[(size_t)pair * 5 * NP + i] = m + logf(sum);
+}
+__global__ __launch_bounds__(256) void k_assign_col_lse(const float* __restrict__ sim, const int* __restrict__ lens,
+                                                        int NP, float* __restrict__ ws) {
+  __shared__ float s_m[4][64], s_s[4][64];
+  const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  float m = -INFINITY, sum = 0.f;
+  if (j < n1) {
+    const float* col = sim + (size_t)pair * NP * NP + j;
+    for (int i = rg; i < n0; i += 4) {
+      const float v = col[(size_t)i * NP];
+      const float mn = fmaxf(m, v);
+      sum = sum * expf(m - mn) + expf(v - mn);
+      m = mn;
+    }
+  }
+  s_m[rg][cl] = m; s_s[rg][cl] = sum;
+  __syncthreads();
+  if (rg == 0 && j < n1) {
+    float M = s_m[0][cl];
+    for (int g = 1; g < 4; ++g) M = fmaxf(M, s_m[g][cl]);
+    float S = 0.f;
+    for (int g = 0; g < 4; ++g) if (s_m[g][cl] > -INFINITY) S += s_s[g][cl] * expf(s_m[g][cl] - M);
+    ws[(size_t)pair * 5 * NP + NP + j] = M + logf(S);
+  }
+}
+// row arg-max of  S_ij = (sim - lse_row_i) + (sim - lse_col_j) + ls0_i + ls1_j ; first index wins ties (torch.max)
+__global__ __launch_bounds__(256) void k_assign_row_arg(const float* __restrict__ sim, const float* __restrict__ logsig,
+                                                        const int* __restrict__ lens, int NP, float* __restrict__ ws) {
+  const int pair = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  if (i >= n0) return;
+  float* w = ws + (size_t)pair * 5 * NP;
+  const float* row = sim + ((size_t)pair * NP + i) * NP;
+  const float* ls1 = logsig + (size_t)(2 * pair + 1) * NP;
+  const float li = w[i], ls0 = logsig[(size_t)(2 * pair) * NP + i];
+  float best = -INFINITY;
+  int bj = 0x7fffffff;
+  for (int j = lane; j < n1; j += 64) {
+    const float v = ((row[j] - li) + (row[j] - w[NP + j])) + (ls0 + ls1[j]);
+    if (v > best) { best = v; bj = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oj = __shfl_xor(bj, o, 64);
+    if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+  }
+  if (lane == 0) { w[2 * NP + i] = best; reinterpret_cast<int*>(w)[3 * NP + i] = bj; }
+}
+__global__ __launch_bounds__(256) void k_assign_col_arg(const float* __restrict__ sim, const float* __restrict__ logsig,
+                                                        const int* __restrict__ lens, int NP, float* __restrict__ ws) {
+  __shared__ float s_v[4][64];
+  __shared__ int s_i[4][64];
+  const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  float* w = ws + (size_t)pair * 5 * NP;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (j < n1) {
+    const float* col = sim + (size_t)pair * NP * NP + j;
+    const float* ls0 = logsig + (size_t)(2 * pair) * NP;
+    const float lj = w[NP + j], ls1 = logsig[(size_t)(2 * pair + 1) * NP + j];
+    for (int i = rg; i < n0; i += 4) {
+      const float sv = col[(size_t)i * NP];
+      const float v = ((sv - w[i]) + (sv - lj)) + (ls0[i] + ls1);
+      if (v > best) { best = v; bi = i; }
+    }
+  }
+  s_v[rg][cl] = best; s_i[rg][cl] = bi;
+  __syncthreads();
+  if (rg == 0 && j < n1) {
+    for (int g = 1; g < 4; ++g)
+      if (s_v[g][cl] > best || (s_v[g][cl] == best && s_i[g][cl] < bi)) { best = s_v[g][cl]; bi = s_i[g][cl]; }
+    reinterpret_cast<int*>(w)[4 * NP + j] = bi;
+  }
+}
+// filter_matches(scores, 0.1): mutual check, mscores0 = mutual ? exp(max0) : 0, matches0 = valid ? m0 : -1.
+__global__ void k_assign_final(const int* __restrict__ lens, int NP, const float* __restrict__ ws, int max_kp,
+                               float thr, int32_t* __restrict__ matches0, float* __restrict__ mscores0) {
+  const int pair = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_kp) return;
+  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  const float* w = ws + (size_t)pair * 5 * NP;
+  int mj = -1;
+  float ms = 0.f;
+  if (i < n0 && n1 > 0) {
+    const int j = reinterpret_cast<const int*>(w)[3 * NP + i];
+    const bool mutual = reinterpret_cast<const int*>(w)[4 * NP + j] == i;
+    ms = mutual ? expf(w[2 * NP + i]) : 0.f;
+    mj = (mutual && ms > thr) ? j : -1;
+  }
+  matches0[(size_t)pair * max_kp + i] = mj;
+  mscores0[(size_t)pair * max_kp + i] = ms;
+}
+void launch_lg_assign(const float* sim, const float* logsig, const int* lens, LgDims d, float* ws, int max_kp,
+                      int32_t* matches0, float* mscores0, float thr, hipStream_t s) {
+  const int P = d.S / 2;
+  hipLaunchKernelGGL(k_assign_row_lse, dim3(d.NP / 4, P), dim3(256), 0, s, sim, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_col_lse, dim3(d.NP / 64, P), dim3(256), 0, s, sim, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_row_arg, dim3(d.NP / 4, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_col_arg, dim3(d.NP / 64, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr,
+                     matches0, mscores0);
+}
+
+}  // namespace sship

@@ -1,0 +1,422 @@
+// SuperPoint non-GEMM kernels: conv1a (u8 -> 64 ch), heatmap softmax + 9x9 NMS + threshold + candidate
+// compaction, radix-select/bitonic top-k, descriptor gather, dense-grid export.  gfx950 only.
+#include "kernels.h"
+
+namespace sship {
+
+// ---------------------------------------------------------------------------------------------------
+// conv1a: u8 image -> relu(conv3x3(img/255)) , 64 channels, channels-last fp16.
+// reference: utils/convert_superpoint_to_onnx.py:38,53 + preprocess src/SuperPoint.cc:768-780.
+// Memory-bound (writes 128 B/pixel).  A thread owns 4 consecutive pixels x 8 channels; 8 adjacent lanes
+// cover the 64 channels of a pixel so every store instruction writes 1 KiB contiguous.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv1a(const uint8_t* __restrict__ img, const float* __restrict__ w,
+                                                const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                int B, int H, int W) {
+  __shared__ float s_w[9 * 64];  // [tap][cout]
+  for (int i = threadIdx.x; i < 576; i += 256) s_w[i] = w[i];
+  __syncthreads();
+  const int grp = threadIdx.x & 7;
+  const int q = blockIdx.x * 32 + (threadIdx.x >> 3);  // quad index over B*H*ceil(W/4)
+  const int qw = (W + 3) >> 2;
+  if (q >= B * H * qw) return;
+  const int xq = q % qw, y = (q / qw) % H, b = q / (qw * H);
+  const int x0 = xq * 4;
+  float in[3][6];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 6; ++dx) {
+      const int yy = y + dy - 1, xx = x0 + dx - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        // OpenCV 8u->32f convertTo: one fp32 multiply; the fp16 engine then sees the fp16-rounded value.
+        v = (float)(_Float16)((float)img[((size_t)b * H + yy) * W + xx] * (1.0f / 255.0f));
+      }
+      in[dy][dx] = v;
+    }
+  float wr[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) wr[t][c] = s_w[t * 64 + grp * 8 + c];
+  float bb[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) bb[c] = bias[grp * 8 + c];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    if (x0 + px >= W) break;
+    float a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = fmaf(in[dy][px + dx], wr[dy * 3 + dx][c], a[c]);
+    h8_t o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (_Float16)fmaxf(a[c] + bb[c], 0.f);
+    *reinterpret_cast<h8_t*>(out + (((size_t)b * H + y) * W + x0 + px) * 64 + grp * 8) = o;
+  }
+}
+
+void launch_conv1a(const uint8_t* img, const float* w, const float* bias, _Float16* out, int B, int H, int W,
+                   hipStream_t s) {
+  const int quads = B * H * ((W + 3) / 4);
+  hipLaunchKernelGGL(k_conv1a, dim3((quads + 31) / 32), dim3(256), 0, s, img, w, bias, out, B, H, W);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Heatmap tile kernel: softmax(65) -> drop dustbin -> depth-to-space -> (2R+1)^2 max-pool NMS ->
+// threshold / border -> candidate compaction.   reference: convert_superpoint_to_onnx.py:77-87 (in-graph)
+// + src/SuperPoint.cc:696-702 (host scan).  HBM-bound: reads 65 logits per cell once (+ halo cells),
+// writes only the surviving candidates (and, on request, the dense post-NMS map for sship_sp_dense).
+//
+// Tile = 32 x 64 pixels (4 x 8 cells) + an 8-pixel (1-cell) halo; radius <= 8.
+// Two loaders share the NMS code: from logits (production) and from a score map (sship_nms / stage tests).
+// Candidate key = (score bits << 32) | (h*W + w): descending key order == std::greater<pair<float,
+// pair<int,int>>> (SuperPoint.cc:703) because scores are positive floats.
+// ---------------------------------------------------------------------------------------------------
+constexpr int NT_H = 32, NT_W = 64, NHALO = 8, NLH = NT_H + 2 * NHALO, NLW = NT_W + 2 * NHALO, NLS = NLW + 1;
+
+
+template <int LOADER>
+__global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
+  __shared__ float s_s[NLH * NLS];
+  __shared__ float s_r[NLH * NT_W];
+  const int tiles_x = (a.W + NT_W - 1) / NT_W, tiles_y = (a.H + NT_H - 1) / NT_H;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int x0 = tx * NT_W - NHALO, y0 = ty * NT_H - NHALO;  // tile origin incl. halo (multiple of 8)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if constexpr (LOADER == 0) {
+    const int Hc = a.H >> 3, Wc = a.W >> 3;
+    const int cy0 = y0 >> 3, cx0 = x0 >> 3;  // may be -1
+    for (int cell = wave; cell < (NLH / 8) * (NLW / 8); cell += 4) {
+      const int cyl = cell / (NLW / 8), cxl = cell % (NLW / 8);
+      const int cy = cy0 + cyl, cx = cx0 + cxl;
+      float sc = -INFINITY;
+      if (cy >= 0 && cy < Hc && cx >= 0 && cx < Wc) {
+        const float* lp = a.logits + ((size_t)(b * Hc + cy) * Wc + cx) * a.ls;
+        const float v = lp[lane];
+        const float d = lp[64];
+        const float m = fmaxf(wave_max(v), d);
+        const float e = expf(v - m);
+        const float sum = wave_sum(e) + expf(d - m);
+        sc = e / sum;
+      }
+      s_s[(cyl * 8 + (lane >> 3)) * NLS + cxl * 8 + (lane & 7)] = sc;
+    }
+  } else {
+    for (int i = tid; i < NLH * NLW; i += 256) {
+      const int ly = i / NLW, lx = i % NLW;
+      const int gy = y0 + ly, gx = x0 + lx;
+      float sc = -INFINITY;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) sc = a.scores_in[((size_t)b * a.H + gy) * a.W + gx];
+      s_s[ly * NLS + lx] = sc;
+    }
+  }
+  __syncthreads();
+  const int R = a.radius;
+  // row max over [x-R, x+R] for the 64 interior columns of all 48 rows
+  for (int i = tid; i < NLH * NT_W; i += 256) {
+    const int ly = i / NT_W, lx = (i % NT_W) + NHALO;
+    float m = -INFINITY;
+    for (int d = -R; d <= R; ++d) m = fmaxf(m, s_s[ly * NLS + lx + d]);
+    s_r[ly * NT_W + (lx - NHALO)] = m;
+  }
+  __syncthreads();
+  for (int i = tid; i < NT_H * NT_W; i += 256) {
+    const int iy = i / NT_W, ix = i % NT_W;
+    const int ly = iy + NHALO;
+    const int gy = y0 + ly, gx = x0 + NHALO + ix;
+    if (gy >= a.H || gx >= a.W) continue;
+    float m = -INFINITY;
+    for (int d = -R; d <= R; ++d) m = fmaxf(m, s_r[(ly + d) * NT_W + ix]);
+    const float s = s_s[ly * NLS + ix + NHALO];
+    const bool is_max = (R <= 0) || (s == m);
+    const size_t o = ((size_t)b * a.H + gy) * a.W + gx;
+    if (a.scores_raw_out) a.scores_raw_out[o] = s;
+    if (a.scores_out) a.scores_out[o] = is_max ? s : 0.0f;
+    if (a.cand && is_max && s >= a.thr_f && gy >= a.border && gy < a.H - a.border && gx >= a.border &&
+        gx < a.W - a.border) {
+      const int idx = atomicAdd(&a.cand_count[b], 1);
+      if (idx < a.cap)
+        a.cand[(size_t)b * a.cap + idx] =
+            ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(gy * a.W + gx);
+    }
+  }
+}
+
+float threshold_as_float(double thr) {
+  // smallest float f such that (double)f > thr   (SuperPoint.cc:700: `score > keypoint_threshold_`)
+  float f = (float)thr;
+  while ((double)f > thr) f = nextafterf(f, -INFINITY);
+  while (!((double)f > thr)) f = nextafterf(f, INFINITY);
+  return f;
+}
+
+void launch_nms_tile(int loader, const NmsArgs& a, hipStream_t s) {
+  const int tiles = a.B * ((a.W + NT_W - 1) / NT_W) * ((a.H + NT_H - 1) / NT_H);
+  if (loader == 0)
+    hipLaunchKernelGGL(k_nms_tile<0>, dim3(tiles), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Top-k: one 1024-thread workgroup per image.  8-pass MSB radix select finds the K-th largest 64-bit key
+// (keys are unique), the K keys >= it are compacted into LDS, bitonic-sorted descending, and turned into
+// keypoints + cells.   reference: src/SuperPoint.cc:703-719.
+// ---------------------------------------------------------------------------------------------------
+
+
+__global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
+  __shared__ unsigned long long s_key[kMaxKp];
+  __shared__ int s_hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_remaining, s_cnt;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int M = min(a.cand_count[b], a.cap);
+  const int K = min(M, a.max_kp);
+  if (a.n_cand_out && tid == 0) a.n_cand_out[b] = a.cand_count[b];
+  if (tid == 0) a.n_out[b] = K;
+  if (K == 0) return;
+  const unsigned long long* cand = a.cand + (size_t)b * a.cap;
+  unsigned long long thresh = 0;
+  if (M > K) {
+    if (tid == 0) { s_prefix = 0; s_remaining = K; }
+    for (int pass = 0; pass < 8; ++pass) {
+      if (tid < 256) s_hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      const int shift = 56 - 8 * pass;
+      for (int i = tid; i < M; i += 1024) {
+        const unsigned long long k = cand[i];
+        if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & 255)], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int rem = s_remaining, cum = 0, d = 255;
+        for (; d > 0; --d) {
+          if (cum + s_hist[d] >= rem) break;
+          cum += s_hist[d];
+        }
+        s_remaining = rem - cum;
+        s_prefix = (prefix << 8) | (unsigned)d;
+      }
+      __syncthreads();
+    }
+    thresh = s_prefix;
+  }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int i = tid; i < M; i += 1024) {
+    const unsigned long long k = cand[i];
+    if (k >= thresh) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      if (pos < kMaxKp) s_key[pos] = k;
+    }
+  }
+  int P2 = 1;
+  while (P2 < K) P2 <<= 1;
+  __syncthreads();
+  for (int i = K + tid; i < P2; i += 1024) s_key[i] = 0ull;
+  __syncthreads();
+  // bitonic sort, descending
+  for (int size = 2; size <= P2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < (P2 >> 1); i += 1024) {
+        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = s_key[lo], y = s_key[hi];
+        if ((x < y) == desc) { s_key[lo] = y; s_key[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < K; i += 1024) {
+    const unsigned long long k = s_key[i];
+    const float score = __uint_as_float((unsigned)(k >> 32));
+    const unsigned idx = (unsigned)(k & 0xffffffffu);
+    const int h = idx / a.score_w, w = idx % a.score_w;
+    float* kp = a.kp_xys + ((size_t)b * a.max_kp + i) * 3;
+    kp[0] = (float)w * a.scale_x;   // cv::KeyPoint(w * scale_x, h * scale_y, 1, -1, score)
+    kp[1] = (float)h * a.scale_y;
+    kp[2] = score;
+    a.cell_h[(size_t)b * a.max_kp + i] = min(h / 8, a.desc_h - 1);
+    a.cell_w[(size_t)b * a.max_kp + i] = min(w / 8, a.desc_w - 1);
+  }
+}
+
+void launch_topk(const TopkArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_topk, dim3(B), dim3(1024), 0, s, a);
+}
+
+// Threshold scan of a dense score map (stage API sship_select_topk; SuperPoint.cc:696-702).
+__global__ void k_threshold_scan(const float* __restrict__ scores, int H, int W, float thr_f, int border,
+                                 unsigned long long* cand, int* cand_count, int cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * W) return;
+  const int h = i / W, w = i % W;
+  if (h < border || h >= H - border || w < border || w >= W - border) return;
+  const float s = scores[i];
+  if (s >= thr_f) {
+    const int idx = atomicAdd(cand_count, 1);
+    if (idx < cap) cand[idx] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)i;
+  }
+}
+void launch_threshold_scan(const float* scores, int H, int W, float thr_f, int border, unsigned long long* cand,
+                           int* cand_count, int cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_threshold_scan, dim3((H * W + 255) / 256), dim3(256), 0, s, scores, H, W, thr_f, border,
+                     cand, cand_count, cap);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Descriptor gather.  reference: src/DescriptorGather.cu:14-56 (one block / keypoint, 2-byte loads 16 KB
+// apart, grid read twice).  Here the grid is channels-last, so a keypoint is ONE contiguous 512-B row: a
+// wave reads it with a single 8-B/lane coalesced load, reduces in registers, writes 512 B.  HBM-bound:
+// algorithmic bytes = n*(512 + 512 + 8).
+// RAW = 1: the row is the un-normalised convDb output; apply the dense F.normalize (exporter :88-89, incl.
+// its fp16 rounding) first, then the gather's own renormalisation - the reference's two-step arithmetic,
+// evaluated only for the selected cells.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load4(const _Float16* p, float (&v)[4]) {
+  const h4_t x = *reinterpret_cast<const h4_t*>(p);
+  v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3];
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(256) void k_gather_hwc(const _Float16* __restrict__ grid, int C, int gh, int gw,
+                                                    size_t img_stride, const int* __restrict__ cell_h,
+                                                    const int* __restrict__ cell_w, const int* __restrict__ n_dev,
+                                                    int n_host, int max_kp, _Float16* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int n = n_dev ? n_dev[b] : n_host;
+  if (i >= n) return;
+  const int ch = cell_h[(size_t)b * max_kp + i], cw = cell_w[(size_t)b * max_kp + i];
+  const _Float16* row = grid + (size_t)b * img_stride + ((size_t)ch * gw + cw) * C;
+  _Float16* orow = out + ((size_t)b * max_kp + i) * C;
+  {  // C <= 256 (checked by the caller): one trip
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c = lane * 4;
+    if (c < C) load4(row + c, v);
+    if (RAW) {
+      const float ss = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+      const float denom = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize(p=2, dim=1, eps=1e-12)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)(v[e] / denom);  // the fp16 dense grid value
+    }
+    const float ss2 = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    const float inv = rsqrtf(ss2 + 1e-12f);
+    if (c < C) *reinterpret_cast<h4_t*>(orow + c) = to_h4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+  }
+}
+
+void launch_gather_hwc(bool raw, const _Float16* grid, int C, int gh, int gw, size_t img_stride, const int* cell_h,
+                       const int* cell_w, const int* n_dev, int n_host, int max_kp, int B, _Float16* out,
+                       hipStream_t s) {
+  const int nmax = n_dev ? max_kp : n_host;
+  if (nmax <= 0) return;
+  dim3 grid_dim((nmax + 3) / 4, B);
+  if (raw)
+    hipLaunchKernelGGL(k_gather_hwc<true>, grid_dim, dim3(256), 0, s, grid, C, gh, gw, img_stride, cell_h, cell_w,
+                       n_dev, n_host, max_kp, out);
+  else
+    hipLaunchKernelGGL(k_gather_hwc<false>, grid_dim, dim3(256), 0, s, grid, C, gh, gw, img_stride, cell_h, cell_w,
+                       n_dev, n_host, max_kp, out);
+}
+
+// CHW grid (the reference engine's layout, kept for the 1:1 launch_gather_descriptors entry point): the
+// 2-byte loads are inherently 2*gh*gw bytes apart; each value is read ONCE into a register (the CUDA kernel
+// reads the column twice) and a wave, not a 256-thread block + shared-memory tree, owns a keypoint.
+__global__ __launch_bounds__(256) void k_gather_chw(const _Float16* __restrict__ grid, int C, int gh, int gw,
+                                                    const int* __restrict__ cell_h, const int* __restrict__ cell_w,
+                                                    int n, _Float16* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const size_t plane = (size_t)gh * gw;
+  const size_t base = (size_t)cell_h[i] * gw + cell_w[i];
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  float ss = 0.f;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e * 64 + lane;  // lanes walk adjacent channel planes
+      const float t = c < C ? (float)grid[c * plane + base] : 0.f;
+      ss += t * t;
+      if (c0 == 0) v[e] = t;  // C <= 256 (the SuperPoint case): the column is read exactly once
+    }
+  }
+  const float inv = rsqrtf(wave_sum(ss) + 1e-12f);
+  for (int c0 = 0; c0 < C; c0 += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e * 64 + lane;
+      if (c < C) {
+        const float t = (c0 == 0) ? v[e] : (float)grid[c * plane + base];
+        out[(size_t)i * C + c] = (_Float16)(t * inv);
+      }
+    }
+  }
+}
+void launch_gather_chw(const _Float16* grid, int C, int gh, int gw, const int* cell_h, const int* cell_w, int n,
+                       _Float16* out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_chw, dim3((n + 3) / 4), dim3(256), 0, s, grid, C, gh, gw, cell_h, cell_w, n, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dense exports for sship_sp_dense (stage/parity API; not on the throughput path).
+// ---------------------------------------------------------------------------------------------------
+// raw channels-last fp16 [B, Hc, Wc, 256] -> F.normalize'd CHW fp16 [B, 256, Hc, Wc] (the engine's layout).
+__global__ __launch_bounds__(256) void k_desc_dense_chw(const _Float16* __restrict__ raw, int cells_per_img, int B,
+                                                        _Float16* __restrict__ out) {
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (cell >= B * cells_per_img) return;
+  const int b = cell / cells_per_img, ci = cell % cells_per_img;
+  float v[4];
+  load4(raw + (size_t)cell * 256 + lane * 4, v);
+  const float ss = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+  const float denom = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    out[((size_t)b * 256 + lane * 4 + e) * cells_per_img + ci] = (_Float16)(v[e] / denom);
+}
+void launch_desc_dense_chw(const _Float16* raw, int cells_per_img, int B, _Float16* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_desc_dense_chw, dim3((B * cells_per_img + 3) / 4), dim3(256), 0, s, raw, cells_per_img, B, out);
+}
+
+// logits channels-last padded [B*cells, ls] f32 -> [B, 65, cells] f32
+__global__ void k_logits_chw(const float* __restrict__ in, int ls, int cells_per_img, int B, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * cells_per_img * 65) return;
+  const int ci = i % cells_per_img, c = (i / cells_per_img) % 65, b = i / (cells_per_img * 65);
+  out[i] = in[((size_t)b * cells_per_img + ci) * ls + c];
+}
+void launch_logits_chw(const float* in, int ls, int cells_per_img, int B, float* out, hipStream_t s) {
+  const int n = B * cells_per_img * 65;
+  hipLaunchKernelGGL(k_logits_chw, dim3((n + 255) / 256), dim3(256), 0, s, in, ls, cells_per_img, B, out);
+}
+
+// 3-channel BGR u8 -> gray u8 (cv::COLOR_BGR2GRAY fixed-point: (B*1868 + G*9617 + R*4899 + 8192) >> 14).
+__global__ void k_bgr2gray(const uint8_t* __restrict__ in, int n, uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int bb = in[3 * i], g = in[3 * i + 1], r = in[3 * i + 2];
+  out[i] = (uint8_t)((bb * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+}
+void launch_bgr2gray(const uint8_t* in, int n, uint8_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_bgr2gray, dim3((n + 255) / 256), dim3(256), 0, s, in, n, out);
+}
+
+}  // namespace sship

@@ -1,0 +1,117 @@
+"""Synthetic (seeded) weights + safetensors IO for the HIP front-end.
+
+The reference's real weights are missing blobs (/root/reference/.MISSING_LARGE_BLOBS) and there
+is no network, so parity and perf use shape-exact seeded state dicts with the reference's key
+layout (SuperPoint: utils/convert_superpoint_to_onnx.py:38-49; LightGlue: upstream checkpoint
+names).  Real weights dropped in as safetensors load through the same path
+(the reference ships utils/export_safetensors.py for the .pth -> safetensors step).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+SP_SHAPES = {
+    "conv1a": (64, 1, 3, 3), "conv1b": (64, 64, 3, 3),
+    "conv2a": (64, 64, 3, 3), "conv2b": (64, 64, 3, 3),
+    "conv3a": (128, 64, 3, 3), "conv3b": (128, 128, 3, 3),
+    "conv4a": (128, 128, 3, 3), "conv4b": (128, 128, 3, 3),
+    "convPa": (256, 128, 3, 3), "convPb": (65, 256, 1, 1),
+    "convDa": (256, 128, 3, 3), "convDb": (256, 256, 1, 1),
+}
+
+LG_LAYERS = 9
+LG_DIM = 256
+LG_HEADS = 4
+
+
+def make_superpoint_weights(seed: int = 0, peak_gain: float = 8.0) -> dict:
+    """He-uniform conv weights from a CPU generator (bit-reproducible across machines).
+
+    ``peak_gain`` scales convPb so the 65-way softmax is peaked enough for the 9x9 NMS and
+    the 0.005 threshold to be meaningful (a default-init head gives a near-uniform heatmap
+    whose every pixel is > 0.005 - SURVEY.md 'Hard parts').
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = {}
+    for name, shp in SP_SHAPES.items():
+        fan_in = shp[1] * shp[2] * shp[3]
+        bound = math.sqrt(6.0 / fan_in)  # gain sqrt(2) he-uniform keeps ReLU activations O(1)
+        w = (torch.rand(shp, generator=g, dtype=torch.float32) * 2 - 1) * bound
+        b = (torch.rand(shp[0], generator=g, dtype=torch.float32) * 2 - 1) * 0.05
+        if name == "convPb":
+            w = w * peak_gain
+        sd[name + ".weight"] = w.contiguous()
+        sd[name + ".bias"] = b.contiguous()
+    return sd
+
+
+def _lin(g, out_f, in_f, gain=1.0, bias_scale=0.02):
+    bound = gain * math.sqrt(3.0 / in_f)
+    w = (torch.rand((out_f, in_f), generator=g, dtype=torch.float32) * 2 - 1) * bound
+    b = (torch.rand((out_f,), generator=g, dtype=torch.float32) * 2 - 1) * bias_scale
+    return w.contiguous(), b.contiguous()
+
+
+def make_lightglue_weights(seed: int = 1, residual_gain: float = 0.05, assign_gain: float = 24.0) -> dict:
+    """Seeded LightGlue(features='superpoint') state dict, upstream key layout.
+
+    ``residual_gain`` keeps each block's update small against the unit-norm descriptor stream and
+    ``assign_gain`` makes final_proj a scaled near-identity, so the random-weight matcher behaves
+    like a sharpened mutual-nearest-neighbour matcher: synthetic stereo pairs then produce a
+    realistic number of confident matches instead of an all -1 output.
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = {}
+    sd["posenc.Wr.weight"] = (torch.randn((32, 2), generator=g, dtype=torch.float32) * 1.0).contiguous()
+    d = LG_DIM
+    for i in range(LG_LAYERS):
+        p = f"transformers.{i}.self_attn."
+        sd[p + "Wqkv.weight"], sd[p + "Wqkv.bias"] = _lin(g, 3 * d, d)
+        sd[p + "out_proj.weight"], sd[p + "out_proj.bias"] = _lin(g, d, d)
+        sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"] = _lin(g, 2 * d, 2 * d)
+        sd[p + "ffn.1.weight"] = (1.0 + 0.1 * torch.randn(2 * d, generator=g)).contiguous()
+        sd[p + "ffn.1.bias"] = (0.05 * torch.randn(2 * d, generator=g)).contiguous()
+        sd[p + "ffn.3.weight"], sd[p + "ffn.3.bias"] = _lin(g, d, 2 * d, gain=residual_gain, bias_scale=0.002)
+        p = f"transformers.{i}.cross_attn."
+        sd[p + "to_qk.weight"], sd[p + "to_qk.bias"] = _lin(g, d, d)
+        sd[p + "to_v.weight"], sd[p + "to_v.bias"] = _lin(g, d, d)
+        sd[p + "to_out.weight"], sd[p + "to_out.bias"] = _lin(g, d, d)
+        sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"] = _lin(g, 2 * d, 2 * d)
+        sd[p + "ffn.1.weight"] = (1.0 + 0.1 * torch.randn(2 * d, generator=g)).contiguous()
+        sd[p + "ffn.1.bias"] = (0.05 * torch.randn(2 * d, generator=g)).contiguous()
+        sd[p + "ffn.3.weight"], sd[p + "ffn.3.bias"] = _lin(g, d, 2 * d, gain=residual_gain, bias_scale=0.002)
+    # Only log_assignment[LG_LAYERS-1] is used with depth_confidence = -1
+    # (utils/convert_lightglue_to_onnx.py:71-74); the others exist in the checkpoint.
+    for i in range(LG_LAYERS):
+        p = f"log_assignment.{i}."
+        w, b = _lin(g, d, d, gain=0.2)
+        sd[p + "final_proj.weight"] = (w + assign_gain * torch.eye(d)).contiguous()
+        sd[p + "final_proj.bias"] = b
+        sd[p + "matchability.weight"], sd[p + "matchability.bias"] = _lin(g, 1, d, gain=1.0)
+        sd[p + "matchability.bias"] = sd[p + "matchability.bias"] + 2.0
+    return sd
+
+
+def save_safetensors(sd: dict, path: str) -> None:
+    from safetensors.torch import save_file
+
+    save_file({k: v.contiguous() for k, v in sd.items()}, path)
+
+
+def load_safetensors(path: str) -> dict:
+    from safetensors.torch import load_file
+
+    return load_file(path)
+
+
+def state_dict_sha256(sd: dict) -> str:
+    """SHA-256 over the raw little-endian bytes of every tensor in sorted-key order."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].contiguous().numpy().tobytes())
+    return h.hexdigest()
