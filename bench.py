@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py - stereo pairs/sec of the front-end hot path (SuperPoint x2 + select + gather + LightGlue)
+on 1376x376 KITTI-shaped synthetic frames (BASELINE.json metric / configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is ONE call of sship_frontend_batch_device over `--pairs` stereo pairs that are already resident in
+HBM (the reference's unit of work: 1x extract_stereo + 1x device match, src/StereoFrontEnd.cc:14,33).
+Independent pairs shard across ranks with no data-path collective (weak scaling: every rank runs the same
+batch); `value` = all pairs of all ranks / max-over-ranks wall time.
+
+Prints ONE JSON line with the driver's fields plus
+  roofline     : the dominant kernel (conv1b: 3x3 64->64 + pool implicit GEMM, 43 % of SuperPoint's FLOPs),
+                 timed live with HIP events on its own stream via sship_sp_bench_layer
+  cpu_baseline : the CPU oracle (kind "port") on this box's host cores, bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 376, 1376
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md (never the 2:1-sparse figure)
+HBM_PEAK_GBS = 8000.0
+
+
+def sp_flops_per_image(h, w):
+    """2*MAC per image, layer table utils/convert_superpoint_to_onnx.py:38-49."""
+    h2, w2, h4, w4, hc, wc = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
+    mac = (h * w * (9 * 64 + 576 * 64) + h2 * w2 * (576 * 64 * 2) + h4 * w4 * (576 * 128 + 1152 * 128)
+           + hc * wc * (1152 * 128 * 2 + 1152 * 256 * 2 + 256 * 65 + 256 * 256))
+    return 2.0 * mac
+
+
+def lg_flops_per_pair(n):
+    mac = 9 * (2 * n * 1245184 + 1792 * n * n) + 2 * n * 65792 + 256 * n * n
+    return 2.0 * mac
+
+
+def cpu_baseline(spw, lgw, left, right, max_kp, budget_s=20.0):
+    """The CPU oracle on the host cores: same synthetic pair, fp32, all cores."""
+    import numpy as np
+    import torch
+
+    from oracle import hostpath as Hh
+    from oracle import lightglue_ref as LR
+    from oracle import superpoint_ref as R
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one_pair():
+        x = R.preprocess_u8(torch.from_numpy(np.stack([left, right])))
+        with torch.no_grad():
+            s, d = R.dense_forward(spw, x)
+        d16 = d.half().numpy()
+        feats = []
+        for b in range(2):
+            sel = Hh.select_topk(s[b].numpy(), H, W, 0.005, 4, max_kp, H // 8, W // 8)
+            feats.append((sel["kp"], Hh.gather_normalize(d16[b], sel["cell_h"], sel["cell_w"])))
+        k0 = torch.from_numpy(Hh.normalize_kpts(feats[0][0], W, H))[None]
+        k1 = torch.from_numpy(Hh.normalize_kpts(feats[1][0], W, H))[None]
+        with torch.no_grad():
+            LR.match(lgw, k0, torch.from_numpy(feats[0][1].astype(np.float32))[None], k1,
+                     torch.from_numpy(feats[1][1].astype(np.float32))[None], dtype=torch.float32)
+
+    one_pair()  # warm-up (thread pools, allocator)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 10):
+        t0 = time.perf_counter()
+        one_pair()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed 1376x376 pairs (median of {len(times)}, 1 warm-up), fp32 torch-CPU SuperPoint + "
+                      f"C select/gather + fp32 LightGlue, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=8, help="stereo pairs per step (per GPU), resident in HBM")
+    ap.add_argument("--max-kp", type=int, default=600, help="superpoint.max_keypoints (600 = the KITTI YAML)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from superslam_amd import FrontEndBatch, LightGlue, SuperPoint, _lib
+    from superslam_amd.synth import make_stereo_pair
+    from superslam_amd.weights import make_lightglue_weights, make_superpoint_weights, save_safetensors
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("SUPERSLAM_HIP_DEVICE", str(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    _lib.init(local_rank)
+
+    wdir = os.path.join(ROOT, "gpurun_out", f"bench_weights_r{rank}")
+    os.makedirs(wdir, exist_ok=True)
+    spw, lgw = make_superpoint_weights(0), make_lightglue_weights(1)
+    save_safetensors(spw, os.path.join(wdir, "sp.safetensors"))
+    save_safetensors(lgw, os.path.join(wdir, "lg.safetensors"))
+    P = args.pairs
+    sp = SuperPoint(os.path.join(wdir, "sp.safetensors"), args.max_kp, 0.005, 4, max_batch=2 * P)
+    assert sp.initialize(), sp.last_error
+    lg = LightGlue(os.path.join(wdir, "lg.safetensors"), W, H, max_keypoints=args.max_kp, max_pairs=P)
+    assert lg.initialize(), lg.last_error
+
+    # synthetic KITTI-shaped pairs (seed 1234 + pair index), uploaded once: inputs are HBM-resident when timing starts
+    pairs = [make_stereo_pair(H, W, 1234 + 97 * rank + i) for i in range(P)]
+    imgs = torch.from_numpy(np.stack([im for p in pairs for im in p])).cuda()
+    fe = FrontEndBatch(sp, lg, P, H, W)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        fe.run(imgs, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_kp = fe.n.cpu().numpy()
+    n_match = int((fe.matches0.cpu().numpy() >= 0).sum())
+    total_pairs = world * P * args.steps
+    value = total_pairs / dt
+
+    out = None
+    if rank == 0:
+        # ---- per-stage device time (hipEvents inside the library), single profiled step ----
+        _lib.lib().sship_set_profiling(1)
+        step(); torch.cuda.synchronize()
+        stages = {k: round(v, 4) for k, v in _lib.stage_timings().items()}
+        _lib.lib().sship_set_profiling(0)
+        # ---- roofline of the dominant kernel: conv1b = igemm<3x3, 64->64, +pool> over 2P images ----
+        ms = C.c_float(0)
+        macs = C.c_double(0)
+        _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, 1, 2 * P, H, W, 20, C.byref(ms), C.byref(macs)))
+        ach = 2.0 * macs.value / (ms.value * 1e-3) / 1e12
+        layer_ms = {}
+        for lid, name in enumerate(["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b",
+                                    "convPa", "convPb", "convDa", "convDb"]):
+            m2 = C.c_float(0)
+            _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, lid, 2 * P, H, W, 10, C.byref(m2), None))
+            layer_ms[name] = round(m2.value, 4)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv1b.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "igemm_kernel<3,64,64,8,EpiF16<relu,pool>> (conv1b)", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "launch_ms": round(ms.value, 4), "flops_per_launch": 2.0 * macs.value}
+        flops_pair = 2 * sp_flops_per_image(H, W) + lg_flops_per_pair(args.max_kp)
+        out = {
+            "metric": "stereo pairs/sec (SPx2+LG) at 1376x376", "value": round(value, 2), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: SuperPoint x2 + select + gather + 1x LightGlue on 1376x376 stereo pairs, "
+                                   f"{P} pairs per step per GPU resident in HBM, max_keypoints {args.max_kp}, seeded synthetic weights",
+                       "pairs_per_step": P, "max_keypoints": args.max_kp, "image": [H, W],
+                       "keypoints_found": [int(n_kp.min()), int(n_kp.max())], "matches_last_step": n_match,
+                       "parallelism": f"replicated weights, pairs sharded over {world} rank(s), no data-path collective"},
+            "algorithmic_gflop_per_pair": round(flops_pair / 1e9, 2),
+            "effective_tflops": round(value * flops_pair / 1e12, 2),
+            "stage_ms": stages, "layer_ms": layer_ms,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], args.max_kp)
+        print(json.dumps(out), flush=True)
+    sp.close(); lg.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,6 +208,13 @@ int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs_
 void sship_set_profiling(int on);
 int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
 
+/* Measurement hook for bench.py's roofline line: re-launch ONE layer of the network `iters` times on the
+ * handle's stream, bracketed by hipEvents on that same stream, over the activations left by the previous
+ * sship_sp_* call of shape (batch, h, w); *avg_ms = mean launch duration.  layer: 0 conv1a, 1 conv1b (+pool),
+ * 2 conv2a, 3 conv2b (+pool), 4 conv3a, 5 conv3b (+pool), 6 conv4a, 7 conv4b, 8 convPa, 9 convPb, 10 convDa,
+ * 11 convDb.  *macs receives the layer's multiply-accumulate count for that shape. */
+int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms, double* macs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+"""ctypes binding of libsuperslam_hip.so (the C ABI in include/sship.h).
+
+The product path is the HIP library and nothing else: if it is missing, or no gfx950 device is
+visible, every call raises - there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsuperslam_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_IO, ERR_NOMEM, ERR_POOL_EXHAUSTED, ERR_NO_DEVICE = 1, 2, 3, 4, 5, 6
+
+
+class SshipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"sship error {code}: {msg}")
+        self.code = code
+
+
+class SpConfig(C.Structure):
+    _fields_ = [("weights_path", C.c_char_p), ("max_keypoints", C.c_int), ("keypoint_threshold", C.c_double),
+                ("remove_borders", C.c_int), ("nms_radius", C.c_int), ("pool_slots", C.c_int),
+                ("max_batch", C.c_int)]
+
+
+class Features(C.Structure):
+    _fields_ = [("kp_xys", C.POINTER(C.c_float)), ("n", C.c_int), ("desc_dev", C.c_void_p), ("slot", C.c_int)]
+
+
+_lib = None
+vp, ip, fp = C.c_void_p, C.c_int, C.c_float
+_SIGS = {
+    "sship_init": (ip, [ip]),
+    "sship_version": (ip, []),
+    "sship_last_error": (C.c_char_p, []),
+    "sship_device_synchronize": (ip, []),
+    "sship_pool_create": (ip, [ip, ip, ip, C.POINTER(vp)]),
+    "sship_pool_destroy": (None, [vp]),
+    "sship_pool_acquire": (ip, [vp]),
+    "sship_pool_release": (None, [vp, ip]),
+    "sship_pool_in_use": (ip, [vp]),
+    "sship_pool_slot_ptr": (vp, [vp, ip]),
+    "sship_gather_normalize": (ip, [vp, ip, ip, ip, vp, vp, ip, vp, vp]),
+    "sship_gather_normalize_hwc": (ip, [vp, ip, ip, ip, vp, vp, ip, vp, vp]),
+    "sship_nms": (ip, [vp, ip, ip, ip, ip, vp, vp]),
+    "sship_select_topk": (ip, [vp, ip, ip, ip, ip, C.c_double, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp]),
+    "sship_sp_create": (ip, [C.POINTER(SpConfig), C.POINTER(vp)]),
+    "sship_sp_destroy": (None, [vp]),
+    "sship_sp_pool": (vp, [vp]),
+    "sship_sp_max_keypoints": (ip, [vp]),
+    "sship_sp_extract": (ip, [vp, vp, ip, ip, ip, ip, C.POINTER(Features)]),
+    "sship_sp_extract_stereo": (ip, [vp, vp, vp, ip, ip, ip, ip, C.POINTER(Features), C.POINTER(Features)]),
+    "sship_sp_infer_host": (ip, [vp, vp, ip, ip, ip, ip, vp, vp, C.POINTER(ip)]),
+    "sship_sp_extract_batch_device": (ip, [vp, vp, ip, ip, ip, vp, vp, vp, vp]),
+    "sship_sp_dense": (ip, [vp, vp, ip, ip, ip, vp, vp, vp, vp]),
+    "sship_lg_weights_load": (ip, [C.c_char_p, C.POINTER(vp)]),
+    "sship_lg_weights_retain": (None, [vp]),
+    "sship_lg_weights_release": (None, [vp]),
+    "sship_lg_create": (ip, [vp, ip, ip, ip, ip, C.POINTER(vp)]),
+    "sship_lg_destroy": (None, [vp]),
+    "sship_lg_normalize_keypoints": (ip, [vp, vp, ip, ip, vp]),
+    "sship_lg_match_device": (ip, [vp, vp, ip, ip, vp, vp, ip, ip, vp, vp, vp]),
+    "sship_lg_match_host": (ip, [vp, vp, ip, ip, vp, vp, ip, ip, vp, vp, vp]),
+    "sship_lg_match_batch_device": (ip, [vp, vp, vp, vp, ip, vp, vp, vp]),
+    "sship_filter_matches": (ip, [vp, vp, ip, vp, vp, vp]),
+    "sship_desc_to_host": (ip, [vp, ip, ip, vp]),
+    "sship_frontend_batch_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp, vp]),
+    "sship_sp_bench_layer": (ip, [vp, ip, ip, ip, ip, ip, C.POINTER(fp), C.POINTER(C.c_double)]),
+    "sship_set_profiling": (None, [ip]),
+    "sship_get_stage_timings": (ip, [C.POINTER(C.c_char_p), C.POINTER(fp), ip]),
+    "sship_set_log_callback": (None, [vp]),
+}
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SshipError(ERR_IO, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                     "(hipcc --offload-arch=gfx950); there is no fallback path")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise SshipError(rc, (lib().sship_last_error() or b"").decode(errors="replace"))
+
+
+_inited = False
+
+
+def init(device: int = -1) -> None:
+    """Select the device (SUPERSLAM_HIP_DEVICE / LOCAL_RANK aware).  Raises SshipError without a GPU."""
+    global _inited
+    if device < 0 and "SUPERSLAM_HIP_DEVICE" not in os.environ and "LOCAL_RANK" in os.environ:
+        device = int(os.environ["LOCAL_RANK"])
+    check(lib().sship_init(device))
+    _inited = True
+
+
+def stage_timings() -> dict:
+    labels = (C.c_char_p * 32)()
+    ms = (fp * 32)()
+    n = lib().sship_get_stage_timings(labels, ms, 32)
+    return {labels[i].decode(): ms[i] for i in range(n)}

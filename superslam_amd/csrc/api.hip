@@ -635,6 +635,53 @@ extern "C" int sship_sp_dense(sship_sp* sp, const uint8_t* imgs, int batch, int 
   return SSHIP_OK;
 }
 
+extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms,
+                                    double* macs) {
+  if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 11) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");
+  if (batch > sp->wsB || h != sp->wsH || w != sp->wsW) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: run the network at this shape first");
+  int H2, W2, H4, W4, Hc, Wc;
+  sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
+  hipStream_t s = sp->stream;
+  _Float16 *a1a = sp->a1a.as<_Float16>(), *a1b = sp->a1b.as<_Float16>(), *a2a = sp->a2a.as<_Float16>(),
+           *a2b = sp->a2b.as<_Float16>(), *a3a = sp->a3a.as<_Float16>(), *a3b = sp->a3b.as<_Float16>(),
+           *a4a = sp->a4a.as<_Float16>(), *a4b = sp->a4b.as<_Float16>(), *aPa = sp->aPa.as<_Float16>(),
+           *aDa = sp->aDa.as<_Float16>();
+  auto run = [&]() -> hipError_t {
+    switch (layer) {
+      case 0: launch_conv1a(sp->img.as<uint8_t>(), sp->w1a, sp->b1a, a1a, batch, h, w, s); return hipGetLastError();
+      case 1: return sp_conv3x3(sp->c1b, a1a, a1b, batch, h, w, true, true, s);
+      case 2: return sp_conv3x3(sp->c2a, a1b, a2a, batch, H2, W2, false, true, s);
+      case 3: return sp_conv3x3(sp->c2b, a2a, a2b, batch, H2, W2, true, true, s);
+      case 4: return sp_conv3x3(sp->c3a, a2b, a3a, batch, H4, W4, false, true, s);
+      case 5: return sp_conv3x3(sp->c3b, a3a, a3b, batch, H4, W4, true, true, s);
+      case 6: return sp_conv3x3(sp->c4a, a3b, a4a, batch, Hc, Wc, false, true, s);
+      case 7: return sp_conv3x3(sp->c4b, a4a, a4b, batch, Hc, Wc, false, true, s);
+      case 8: return sp_conv3x3(sp->cPa, a4b, aPa, batch, Hc, Wc, false, true, s);
+      case 9: return sp_conv1x1_f32(sp->cPb, aPa, sp->logits.as<float>(), kLogitStride, batch, Hc, Wc, s);
+      case 10: return sp_conv3x3(sp->cDa, a4b, aDa, batch, Hc, Wc, false, true, s);
+      default: return sp_conv1x1_f16(sp->cDb, aDa, sp->draw.as<_Float16>(), batch, Hc, Wc, s);
+    }
+  };
+  const double px[12] = {(double)h * w, (double)h * w, (double)H2 * W2, (double)H2 * W2, (double)H4 * W4, (double)H4 * W4,
+                         (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc};
+  const double mpp[12] = {9.0 * 64, 576.0 * 64, 576.0 * 64, 576.0 * 64, 576.0 * 128, 1152.0 * 128, 1152.0 * 128,
+                          1152.0 * 128, 1152.0 * 256, 256.0 * 65, 1152.0 * 256, 256.0 * 256};
+  if (macs) *macs = px[layer] * mpp[layer] * batch;
+  SSHIP_HIP_CHECK(run());  // warm
+  hipEvent_t e0, e1;
+  SSHIP_HIP_CHECK(hipEventCreate(&e0));
+  SSHIP_HIP_CHECK(hipEventCreate(&e1));
+  SSHIP_HIP_CHECK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) SSHIP_HIP_CHECK(run());
+  SSHIP_HIP_CHECK(hipEventRecord(e1, s));
+  SSHIP_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SSHIP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *avg_ms = ms / iters;
+  return SSHIP_OK;
+}
+
 // host-image front: upload (pinned) -> gray -> batch path into pool slots -> D2H keypoints.
 static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int h, int w, int stride, int channels,
                            sship_features* const* outs) {

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def weights_dir(tmp_path_factory):
+    """Seeded synthetic weights written as safetensors (regenerated from the seed on every machine)."""
+    from superslam_amd.weights import make_lightglue_weights, make_superpoint_weights, save_safetensors
+
+    d = tmp_path_factory.mktemp("weights")
+    sp = make_superpoint_weights(0)
+    lg = make_lightglue_weights(1)
+    save_safetensors(sp, str(d / "superpoint.safetensors"))
+    save_safetensors(lg, str(d / "lightglue.safetensors"))
+    return {"dir": str(d), "sp_path": str(d / "superpoint.safetensors"), "lg_path": str(d / "lightglue.safetensors"),
+            "sp": sp, "lg": lg}
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")

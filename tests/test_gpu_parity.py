@@ -1,0 +1,402 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle / committed golden vectors.
+
+Bit-exact for integer / index / compare work (NMS mask, threshold, top-k order, cells, pool bookkeeping);
+stated tolerances for fp16 arithmetic:
+  dense descriptors |d| <= 2e-3 & cosine >= 0.9995;  gathered rows <= 1 fp16 ulp vs the oracle on the same grid;
+  mscores0 |d| <= 2e-2;  matches0 agreement >= 99 % (disagreeing rows are near-ties).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hostpath as H  # noqa: E402
+from oracle import lightglue_ref as LR  # noqa: E402
+from oracle import superpoint_ref as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from superslam_amd import _lib
+
+    _lib.init()
+    assert torch.cuda.is_available()
+    return _lib.lib()
+
+
+@pytest.fixture(scope="module")
+def sp(hip, weights_dir):
+    from superslam_amd import SuperPoint
+
+    s = SuperPoint(weights_dir["sp_path"], 600, 0.005, 4, max_batch=2)
+    assert s.initialize(), s.last_error
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def lg(hip, weights_dir):
+    from superslam_amd import LightGlue
+
+    m = LightGlue(weights_dir["lg_path"], 1376, 376, max_keypoints=600, max_pairs=2)
+    assert m.initialize(), m.last_error
+    yield m
+    m.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def ulp16(a, b):
+    """distance in fp16 ulps between two float16 arrays (sign-magnitude aware)."""
+    def key(x):
+        u = x.view(np.uint16).astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7fff), u)
+    return np.abs(key(a) - key(b))
+
+
+# ------------------------------------------------------------------------------------------------------
+# gather (DescriptorGather.cu)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 37, 600, 1024])
+def test_gather_chw_matches_oracle(hip, n):
+    rng = np.random.default_rng(n + 1)
+    gh, gw = 47, 172
+    grid = (rng.standard_normal((256, gh, gw)) * 0.07).astype(np.float16)
+    ch = rng.integers(0, gh, n).astype(np.int32)
+    cw = rng.integers(0, gw, n).astype(np.int32)
+    out = torch.zeros((max(n, 1), 256), dtype=torch.float16, device="cuda")
+    g, a, b = dev(grid), dev(ch) if n else torch.zeros(1, dtype=torch.int32, device="cuda"), \
+        dev(cw) if n else torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = hip.sship_gather_normalize(g.data_ptr(), 256, gh, gw, a.data_ptr(), b.data_ptr(), n, out.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    if n == 0:
+        return
+    ref = H.gather_normalize(grid, ch, cw, tree=True)
+    got = out.cpu().numpy()[:n]
+    d = ulp16(got, ref)
+    print(f"gather chw n={n}: exact {np.mean(d == 0):.4f}, max ulp {d.max()}")
+    assert d.max() <= 1
+    np.testing.assert_allclose(np.linalg.norm(got.astype(np.float32), axis=1), 1.0, atol=2e-3)
+
+
+def test_gather_hwc_matches_oracle(hip):
+    rng = np.random.default_rng(9)
+    gh, gw, n = 60, 94, 600
+    grid = (rng.standard_normal((256, gh, gw)) * 0.07).astype(np.float16)
+    ch = rng.integers(0, gh, n).astype(np.int32)
+    cw = rng.integers(0, gw, n).astype(np.int32)
+    hwc = np.ascontiguousarray(grid.transpose(1, 2, 0))
+    out = torch.zeros((n, 256), dtype=torch.float16, device="cuda")
+    g, a, b = dev(hwc), dev(ch), dev(cw)
+    assert hip.sship_gather_normalize_hwc(g.data_ptr(), 256, gh, gw, a.data_ptr(), b.data_ptr(), n, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    d = ulp16(out.cpu().numpy(), H.gather_normalize(grid, ch, cw, tree=True))
+    print(f"gather hwc: exact {np.mean(d == 0):.4f}, max ulp {d.max()}")
+    assert d.max() <= 1
+
+
+# ------------------------------------------------------------------------------------------------------
+# NMS / select / top-k : bit-exact
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(40, 56), (376, 1376), (96, 248), (33, 65)])
+def test_nms_bit_exact(hip, shape):
+    rng = np.random.default_rng(shape[0])
+    s = rng.random((2,) + shape, dtype=np.float32)
+    s[0, 5:9, 5:9] = 0.999            # plateau
+    s[1] = np.round(s[1] * 8) / 8     # heavy ties
+    x = dev(s)
+    out = torch.empty_like(x)
+    assert hip.sship_nms(x.data_ptr(), 2, shape[0], shape[1], 4, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b in range(2):
+        np.testing.assert_array_equal(got[b], H.nms_maxpool(s[b], 4))
+
+
+def _select_gpu(hip, scores, ih, iw, thr, border, mk, dh, dw):
+    x = dev(scores)
+    kp = torch.zeros((mk, 3), dtype=torch.float32, device="cuda")
+    ch = torch.zeros(mk, dtype=torch.int32, device="cuda")
+    cw = torch.zeros(mk, dtype=torch.int32, device="cuda")
+    n = torch.zeros(2, dtype=torch.int32, device="cuda")
+    rc = hip.sship_select_topk(x.data_ptr(), scores.shape[0], scores.shape[1], ih, iw, thr, border, mk, dh, dw,
+                               kp.data_ptr(), ch.data_ptr(), cw.data_ptr(), n.data_ptr(), n.data_ptr() + 4, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    k = int(n[0])
+    return kp.cpu().numpy()[:k], ch.cpu().numpy()[:k], cw.cpu().numpy()[:k], int(n[1])
+
+
+def test_select_topk_bit_exact_on_golden_cases(hip, golden_dir):
+    g = np.load(os.path.join(golden_dir, "select_cases.npz"))
+    for case in ("ties", "quantised", "empty", "below_thr"):
+        m = g[f"{case}_map"]
+        for mk in (5, 1000):
+            kp, ch, cw, _ = _select_gpu(hip, m, m.shape[0], m.shape[1] + 1, 0.005, 4, mk, m.shape[0] // 8, m.shape[1] // 8)
+            np.testing.assert_array_equal(kp, g[f"{case}_kp_{mk}"], err_msg=f"{case} {mk}")
+            np.testing.assert_array_equal(ch, g[f"{case}_cell_h_{mk}"])
+            np.testing.assert_array_equal(cw, g[f"{case}_cell_w_{mk}"])
+
+
+def test_select_topk_bit_exact_on_reference_score_maps(hip, golden_dir):
+    for name, (h, w) in (("sp_64x64", (64, 64)), ("sp_120x160", (120, 160)), ("sp_96x249", (96, 249))):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        d = g["descriptors"]
+        for mk in (16, 600):
+            kp, ch, cw, _ = _select_gpu(hip, g["scores"], h, w, 0.005, 4, mk, d.shape[1], d.shape[2])
+            np.testing.assert_array_equal(kp, g[f"kp_{mk}"])
+            np.testing.assert_array_equal(ch, g[f"cell_h_{mk}"])
+            np.testing.assert_array_equal(cw, g[f"cell_w_{mk}"])
+
+
+def test_select_topk_full_size_many_candidates(hip):
+    """376x1376, ~50k candidates with many exact ties -> radix select + bitonic path, bit-exact."""
+    rng = np.random.default_rng(3)
+    s = rng.random((376, 1376), dtype=np.float32)
+    s[rng.random(s.shape) < 0.9] = 0
+    s = (np.round(s * 64) / 64).astype(np.float32)
+    for mk in (600, 1024, 4096):
+        kp, ch, cw, nc = _select_gpu(hip, s, 376, 1376, 0.005, 4, mk, 47, 172)
+        r = H.select_topk(s, 376, 1376, 0.005, 4, mk, 47, 172)
+        assert nc == r["n_candidates"]
+        np.testing.assert_array_equal(kp, r["kp"])
+        np.testing.assert_array_equal(ch, r["cell_h"])
+        np.testing.assert_array_equal(cw, r["cell_w"])
+
+
+# ------------------------------------------------------------------------------------------------------
+# SuperPoint network
+# ------------------------------------------------------------------------------------------------------
+def _stats(name, a, b):
+    d = np.abs(a - b)
+    print(f"{name}: max|d| {d.max():.3e} mean|d| {d.mean():.3e} ref max {np.abs(b).max():.3e}")
+    return d
+
+
+@pytest.mark.parametrize("name", ["sp_64x64", "sp_120x160", "sp_96x249"])
+def test_superpoint_dense_vs_reference_vectors(sp, weights_dir, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    img = dev(g["image"][None])
+    scores, desc, logits = sp.dense(img, want_logits=True)
+    torch.cuda.synchronize()
+    logits, desc, scores = logits[0].cpu().numpy(), desc[0].float().cpu().numpy(), scores[0].cpu().numpy()
+    assert scores.shape == g["scores"].shape and desc.shape == g["descriptors"].shape
+    # fp16-arithmetic emulation of the same network (weights + activations rounded to fp16, fp32 accumulate)
+    x = R.preprocess_u8(torch.from_numpy(g["image"])[None])
+    with torch.no_grad():
+        feat = R.encode(weights_dir["sp"], x, emulate_fp16=True)
+        lg16 = R.detector_logits(weights_dir["sp"], feat, emulate_fp16=True)[0].numpy()
+        d16 = R.descriptor_grid(weights_dir["sp"], feat, emulate_fp16=True)[0].numpy()
+    d_l16 = _stats(f"{name} logits vs fp16-emulated oracle", logits, lg16)
+    d_l32 = _stats(f"{name} logits vs reference (fp32)", logits, g["logits"])
+    d_d16 = _stats(f"{name} desc vs fp16-emulated oracle", desc, d16)
+    d_d32 = _stats(f"{name} desc vs reference (fp32)", desc, g["descriptors"].astype(np.float32))
+    cos = (desc * g["descriptors"].astype(np.float32)).sum(0)
+    print(f"{name} desc cosine vs reference: min {cos.min():.6f}")
+    assert d_l16.max() < 2e-2 and d_l32.max() < 0.15     # logits are O(10); fp16 activations
+    assert d_d16.max() < 1.5e-3 and d_d32.max() < 2e-3 and cos.min() > 0.9995
+    # scores: NMS'd heatmap; compare where both agree on survival, and count survival flips
+    both = (scores > 0) & (g["scores"] > 0)
+    flips = ((scores > 0) != (g["scores"] > 0)).sum()
+    print(f"{name} scores: survivors {int((g['scores'] > 0).sum())}, flips {int(flips)}, "
+          f"max|d| on common {np.abs(scores - g['scores'])[both].max():.3e}")
+    assert flips <= 0.02 * (g["scores"] > 0).sum() + 2
+    assert np.abs(scores - g["scores"])[both].max() < 2e-2
+
+
+def test_superpoint_stages_compose_exactly(sp, hip, golden_dir):
+    """extract() == select_topk(NMS'd dense scores) + gather(dense grid) on the library's own tensors:
+    the fused production path and the staged API share arithmetic bit-for-bit."""
+    g = np.load(os.path.join(golden_dir, "sp_120x160.npz"))
+    img = g["image"]
+    f = sp.extract(img)
+    scores, desc = sp.dense(dev(img[None]))
+    torch.cuda.synchronize()
+    s = scores[0].cpu().numpy()
+    r = H.select_topk(s, 120, 160, 0.005, 4, 600, 15, 20)
+    np.testing.assert_array_equal(f.keypoints, r["kp"])
+    ref_rows = H.gather_normalize(desc[0].cpu().numpy(), r["cell_h"], r["cell_w"])
+    from superslam_amd import LightGlue  # noqa: F401
+    got = np.zeros((f.descriptors.count, 256), np.float32)
+    assert hip.sship_desc_to_host(f.descriptors.data, f.descriptors.count, 256, got.ctypes.data) == 0
+    d = ulp16(got.astype(np.float16), ref_rows)
+    print(f"compose: n={len(r['kp'])} gather exact {np.mean(d == 0):.4f} max ulp {d.max()}")
+    assert d.max() <= 1
+
+
+def test_superpoint_extract_vs_oracle_end_to_end(sp, weights_dir):
+    from superslam_amd.synth import make_stereo_pair
+
+    l, r = make_stereo_pair(376, 1376, 1234)
+    fl, fr = sp.extract_stereo(l, r)
+    assert sp.pool_in_use() == 2
+    x = R.preprocess_u8(torch.from_numpy(np.stack([l, r])))
+    with torch.no_grad():
+        s, d = R.dense_forward(weights_dir["sp"], x, emulate_fp16=True)
+    for b, f in enumerate((fl, fr)):
+        ref = H.select_topk(s[b].numpy(), 376, 1376, 0.005, 4, 600, 47, 172)
+        a = {(int(k[0]), int(k[1])) for k in f.keypoints}
+        bset = {(int(k[0]), int(k[1])) for k in ref["kp"]}
+        iou = len(a & bset) / max(1, len(a | bset))
+        print(f"e2e image {b}: n={len(f.keypoints)} ref n={len(ref['kp'])} keypoint IoU {iou:.4f}")
+        assert len(f.keypoints) == 600 and iou > 0.9
+        sc = f.keypoints[:, 2]
+        assert (np.diff(sc) <= 0).all()      # sortedness property (descending response)
+    del fl, fr
+    import gc; gc.collect()
+    assert sp.pool_in_use() == 0            # handles returned their slots
+
+
+def test_superpoint_batch_device_equals_host_api(sp):
+    from superslam_amd.synth import make_stereo_pair
+
+    l, r = make_stereo_pair(120, 160, 5)
+    fl, fr = sp.extract_stereo(l, r)
+    desc, kp, n = sp.extract_batch_device(dev(np.stack([l, r])))
+    torch.cuda.synchronize()
+    for b, f in enumerate((fl, fr)):
+        k = int(n[b])
+        assert k == len(f.keypoints)
+        np.testing.assert_array_equal(kp[b, :k].cpu().numpy(), f.keypoints)
+
+
+def test_extract_edge_cases(sp):
+    flat = np.full((64, 64), 128, np.uint8)
+    f = sp.extract(flat)                   # flat image: plateaus everywhere; must not crash
+    assert len(f.keypoints) <= 600
+    ok, kp, d = sp.infer(np.zeros((9, 9), np.uint8))   # 1x1 cell image
+    assert ok and len(kp) == 0 and d.shape == (0, 256)
+    l = np.zeros((64, 64), np.uint8)
+    a, b = sp.extract_stereo(l, np.zeros((64, 72), np.uint8))   # mismatched pair -> empty, never raises
+    assert len(a.keypoints) == 0 and len(b.keypoints) == 0
+    bgr = np.stack([flat] * 3, -1)
+    f3 = sp.extract(bgr)
+    assert len(f3.keypoints) == len(f.keypoints)
+
+
+# ------------------------------------------------------------------------------------------------------
+# pool (tests/test_descriptor_pool.cc semantics, on the device-backed pool)
+# ------------------------------------------------------------------------------------------------------
+def test_pool_lifo_and_exhaustion(hip):
+    from superslam_amd import DescriptorPool
+
+    p = DescriptorPool(3, 16, 256)
+    a, b, c = p.make(4), p.make(5), p.make(6)
+    assert min(a.slot, b.slot, c.slot) >= 0 and p.in_use() == 3
+    e = p.make(1)
+    assert e.slot == -1 and e.empty()          # exhausted
+    bslot = b.slot
+    del b
+    import gc; gc.collect()
+    assert p.in_use() == 2
+    d = p.make(2)
+    assert d.slot == bslot                     # reuses the freed slot (LIFO)
+    assert p.slot_ptr(99) == 0
+
+
+# ------------------------------------------------------------------------------------------------------
+# LightGlue
+# ------------------------------------------------------------------------------------------------------
+def _lg_case(lg, weights_dir, k0, d0h, k1, d1h, tag, image=(1376, 376)):
+    """k: normalised keypoints [N,2]; the C ABI takes pixel coordinates -> un-normalise exactly-invertibly."""
+    W, Hh = image
+    scale = max(W, Hh) / 2.0
+    px0 = (k0 * scale + np.array([W / 2.0, Hh / 2.0])).astype(np.float32)
+    px1 = (k1 * scale + np.array([W / 2.0, Hh / 2.0])).astype(np.float32)
+    res = lg.match(px0, d0h.astype(np.float32), px1, d1h.astype(np.float32))
+    nk0, nk1 = H.normalize_kpts(px0, W, Hh), H.normalize_kpts(px1, W, Hh)
+    with torch.no_grad():
+        m_ref, s_ref = LR.match(weights_dir["lg"], torch.from_numpy(nk0)[None], torch.from_numpy(d0h.astype(np.float32))[None],
+                                torch.from_numpy(nk1)[None], torch.from_numpy(d1h.astype(np.float32))[None])
+    m_ref, s_ref = m_ref[0].numpy(), s_ref[0].numpy()
+    agree = (res.matches0 == m_ref).mean()
+    ds = np.abs(res.mscores0 - s_ref)
+    print(f"LG {tag}: n0={len(k0)} n1={len(k1)} matched ref {int((m_ref >= 0).sum())} got {int((res.matches0 >= 0).sum())} "
+          f"agreement {agree:.4f} mscores max|d| {ds.max():.3e}")
+    return res, m_ref, s_ref, agree, ds
+
+
+@pytest.mark.parametrize("tag", ["n7x5", "n64x64", "n97x130"])
+def test_lightglue_vs_oracle_selfcheck_vectors(lg, weights_dir, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "lightglue_selfcheck.npz"))
+    res, m_ref, s_ref, agree, ds = _lg_case(lg, weights_dir, g[tag + "_kpts0"].astype(np.float64), g[tag + "_desc0"],
+                                            g[tag + "_kpts1"].astype(np.float64), g[tag + "_desc1"], tag)
+    assert agree >= 0.99 or (res.matches0 != m_ref).sum() <= 1
+    assert ds.max() <= 2e-2
+    q, t, dist = H.filter_matches(res.matches0, res.mscores0)   # reference post-processing on our raw outputs
+    np.testing.assert_array_equal(res.query_idx, q)
+    np.testing.assert_array_equal(res.train_idx, t)
+    np.testing.assert_array_equal(res.distance, dist)
+    assert (np.diff(res.query_idx) > 0).all()
+
+
+def test_lightglue_on_superpoint_features(sp, lg, weights_dir):
+    """Full-size pair: device-descriptor match on real pool slots vs the oracle on the same inputs."""
+    from superslam_amd.synth import make_stereo_pair
+
+    l, r = make_stereo_pair(376, 1376, 1234)
+    fl, fr = sp.extract_stereo(l, r)
+    res = lg.match(fl.keypoints, fl.descriptors, fr.keypoints, fr.descriptors)
+    d0 = lg.descriptors_to_host(fl.descriptors); d1 = lg.descriptors_to_host(fr.descriptors)
+    assert d0.shape == (600, 256)
+    np.testing.assert_allclose(np.linalg.norm(d0, axis=1), 1.0, atol=2e-3)
+    k0 = H.normalize_kpts(fl.keypoints, 1376, 376); k1 = H.normalize_kpts(fr.keypoints, 1376, 376)
+    with torch.no_grad():
+        m_ref, s_ref = LR.match(weights_dir["lg"], torch.from_numpy(k0)[None], torch.from_numpy(d0)[None],
+                                torch.from_numpy(k1)[None], torch.from_numpy(d1)[None])
+    m_ref, s_ref = m_ref[0].numpy(), s_ref[0].numpy()
+    agree = (res.matches0 == m_ref).mean()
+    ds = np.abs(res.mscores0 - s_ref)
+    print(f"LG full: matched ref {int((m_ref >= 0).sum())} got {int((res.matches0 >= 0).sum())} agreement {agree:.4f} "
+          f"mscores max|d| {ds.max():.3e} mean {ds.mean():.3e}")
+    assert agree >= 0.99
+    assert ds.max() <= 2e-2
+    # host-descriptor overload gives the same answer as the device overload
+    res_h = lg.match(fl.keypoints, d0, fr.keypoints, d1)
+    np.testing.assert_array_equal(res_h.matches0, res.matches0)
+    # front-end consumer semantics (StereoFrontEnd.cc:35-48) on real outputs
+    from superslam_amd import process_stereo
+    obs, *_ = process_stereo(sp, lg, l, r)
+    assert obs.has_depth.sum() > 0
+    ok = obs.has_depth == 1
+    assert (obs.keypoints_left[ok, 0] - obs.u_right[ok] >= 1.0).all()
+
+
+def test_lightglue_self_match_is_identity(lg):
+    """Property: matching a set against itself returns the identity with high scores."""
+    rng = np.random.default_rng(11)
+    n = 300
+    kp = np.stack([rng.uniform(10, 1366, n), rng.uniform(10, 366, n)], 1).astype(np.float32)
+    d = rng.standard_normal((n, 256)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    res = lg.match(kp, d, kp, d)
+    assert (res.matches0 == np.arange(n)).mean() > 0.98
+    assert lg.match(kp[:0], d[:0], kp, d).matches0.size == 0    # n = 0 -> empty result, no raise
+
+
+def test_frontend_batch_equals_separate_calls(sp, lg):
+    from superslam_amd import FrontEndBatch
+    from superslam_amd.synth import make_stereo_pair
+
+    pairs = [make_stereo_pair(120, 160, 40 + i) for i in range(2)]
+    imgs = dev(np.stack([im for p in pairs for im in p]))
+    sp2 = sp
+    fe = FrontEndBatch(sp2, lg, 2, 120, 160)
+    fe.run(imgs)
+    torch.cuda.synchronize()
+    for p, (l, r) in enumerate(pairs):
+        fl, fr = sp.extract_stereo(l, r)
+        res = lg.match(fl.keypoints, fl.descriptors, fr.keypoints, fr.descriptors)
+        n0 = int(fe.n[2 * p])
+        assert n0 == len(fl.keypoints) and int(fe.n[2 * p + 1]) == len(fr.keypoints)
+        np.testing.assert_array_equal(fe.kp[2 * p, :n0].cpu().numpy(), fl.keypoints)
+        np.testing.assert_array_equal(fe.matches0[p, :n0].cpu().numpy(), res.matches0)
+        np.testing.assert_allclose(fe.mscores0[p, :n0].cpu().numpy(), res.mscores0, atol=1e-6)
+        assert (fe.matches0[p, n0:].cpu().numpy() == -1).all()

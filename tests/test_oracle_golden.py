@@ -1,0 +1,187 @@
+"""CPU: the oracle against the committed golden vectors (no GPU, no /root/reference at run time)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import hostpath as H
+from oracle import lightglue_ref as L
+from oracle import superpoint_ref as R
+from superslam_amd.weights import make_lightglue_weights, make_superpoint_weights, state_dict_sha256
+
+
+def _meta(golden_dir):
+    with open(os.path.join(golden_dir, "meta.json")) as f:
+        return json.load(f)
+
+
+def test_seeded_weights_are_bit_reproducible(golden_dir):
+    m = _meta(golden_dir)
+    sd = make_superpoint_weights(m["sp_seed"])
+    assert state_dict_sha256(sd) == m["sp_sha256"]
+    assert state_dict_sha256(make_lightglue_weights(m["lg_seed"])) == m["lg_sha256"]
+    for k, v in m["sp_probe"].items():
+        assert sd[k].flatten()[:4].tolist() == v
+
+
+def test_superpoint_restatement_matches_reference_vectors(golden_dir):
+    """The vectors were produced by importing the reference's DenseSuperPoint; fp32 conv results can
+    differ in the last bits between CPUs/thread counts, so compare with a tight float tolerance and
+    require the decisions (NMS survivors, selected keypoints) to be identical."""
+    sd = make_superpoint_weights(0)
+    for name in ("sp_64x64", "sp_120x160", "sp_96x249"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        x = R.preprocess_u8(torch.from_numpy(g["image"])[None])
+        with torch.no_grad():
+            feat = R.encode(sd, x)
+            logits = R.detector_logits(sd, feat)
+            scores, desc = R.dense_forward(sd, x)
+        assert scores.shape[1:] == g["scores"].shape, name  # odd widths: 249 -> 248
+        np.testing.assert_allclose(logits[0].numpy(), g["logits"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(scores[0].numpy(), g["scores"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(desc[0].numpy(), g["descriptors"].astype(np.float32), atol=1e-3)
+        assert ((scores[0].numpy() > 0) == (g["scores"] > 0)).mean() > 0.9999
+
+
+def test_select_and_gather_on_reference_outputs(golden_dir):
+    """Stage-exact: given the reference's score map / descriptor grid, select + gather are bit-exact."""
+    for name, (h, w) in (("sp_64x64", (64, 64)), ("sp_120x160", (120, 160)), ("sp_96x249", (96, 249))):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        d = g["descriptors"]
+        for mk in (16, 600):
+            r = H.select_topk(g["scores"], h, w, 0.005, 4, mk, d.shape[1], d.shape[2])
+            np.testing.assert_array_equal(r["kp"], g[f"kp_{mk}"])
+            np.testing.assert_array_equal(r["hw"], g[f"hw_{mk}"])
+            np.testing.assert_array_equal(r["cell_h"], g[f"cell_h_{mk}"])
+            np.testing.assert_array_equal(r["cell_w"], g[f"cell_w_{mk}"])
+            out = H.gather_normalize(d, r["cell_h"], r["cell_w"])
+            np.testing.assert_array_equal(out.view(np.uint16), g[f"gathered_{mk}"].view(np.uint16))
+    # odd width: keypoint x is rescaled by 249/248 (SuperPoint.cc:707-708)
+    g = np.load(os.path.join(golden_dir, "sp_96x249.npz"))
+    assert np.allclose(g["kp_600"][:, 0], g["hw_600"][:, 1] * np.float32(249 / 248))
+
+
+def _select_python(scores, input_h, input_w, thr, border, max_kp, dh, dw):
+    """Independent transcription of src/SuperPoint.cc:696-719 in pure Python (sorted on the same tuple)."""
+    sh, sw = scores.shape
+    cand = []
+    for h in range(border, sh - border):
+        for w in range(border, sw - border):
+            s = float(scores[h, w])
+            if s > thr:
+                cand.append((np.float32(s), (h, w)))
+    cand.sort(reverse=True)   # std::greater<pair<float, pair<int,int>>>
+    cand = cand[:max_kp]
+    sx = np.float32(input_w) / np.float32(sw)
+    sy = np.float32(input_h) / np.float32(sh)
+    kp = np.array([[np.float32(w) * sx, np.float32(h) * sy, s] for s, (h, w) in cand], np.float32).reshape(-1, 3)
+    ch = np.array([min(h // 8, dh - 1) for _, (h, w) in cand], np.int32)
+    cw = np.array([min(w // 8, dw - 1) for _, (h, w) in cand], np.int32)
+    return kp, ch, cw
+
+
+def test_select_adversarial_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "select_cases.npz"))
+    for case in ("ties", "quantised", "empty", "below_thr"):
+        m = g[f"{case}_map"]
+        for mk in (5, 1000):
+            r = H.select_topk(m, m.shape[0], m.shape[1] + 1, 0.005, 4, mk, m.shape[0] // 8, m.shape[1] // 8)
+            np.testing.assert_array_equal(r["kp"], g[f"{case}_kp_{mk}"])
+            np.testing.assert_array_equal(r["cell_h"], g[f"{case}_cell_h_{mk}"])
+            kp, ch, cw = _select_python(m, m.shape[0], m.shape[1] + 1, 0.005, 4, mk, m.shape[0] // 8, m.shape[1] // 8)
+            np.testing.assert_array_equal(r["kp"], kp)
+            np.testing.assert_array_equal(r["cell_h"], ch)
+            np.testing.assert_array_equal(r["cell_w"], cw)
+    # the hand-built expectations of the "ties" map
+    hw = g["ties_hw_1000"]
+    ties = [tuple(x) for x in hw if g["ties_map"][x[0], x[1]] == np.float32(0.5)]
+    assert ties == [(30, 50), (20, 10), (10, 30), (10, 10)]          # larger h first, then larger w
+    assert (15, 15) not in [tuple(x) for x in hw]                    # float(0.005) > double 0.005 is False?
+    assert (3, 20) not in [tuple(x) for x in hw] and (36, 30) not in [tuple(x) for x in hw]  # border rows
+    assert len(g["empty_kp_5"]) == 0 and len(g["below_thr_kp_5"]) == 0
+
+
+def test_threshold_is_compared_in_double():
+    # float(0.005) = 0.004999999888..., which is NOT > 0.005 (double); the next float up is.
+    m = np.zeros((24, 24), np.float32)
+    m[10, 10] = np.float32(0.005)
+    m[12, 12] = np.nextafter(np.float32(0.005), np.float32(1))
+    r = H.select_topk(m, 24, 24, 0.005, 4, 10, 3, 3)
+    assert [tuple(x) for x in r["hw"]] == [(12, 12)]
+
+
+def test_nms_matches_torch_maxpool():
+    rng = np.random.default_rng(5)
+    s = rng.random((1, 40, 56), dtype=np.float32) * np.float32(0.9)
+    s[0, 5:9, 5:9] = 0.99  # plateau: every member survives
+    ours = H.nms_maxpool(s[0], 4)
+    ref = R.nms(torch.from_numpy(s), 4)[0].numpy()
+    np.testing.assert_array_equal(ours, ref)
+    assert (ours[5:9, 5:9] == np.float32(0.99)).all()
+
+
+def test_gather_tree_vs_sequential_within_one_ulp():
+    rng = np.random.default_rng(6)
+    grid = rng.standard_normal((256, 6, 7)).astype(np.float16)
+    ch = rng.integers(0, 6, 50).astype(np.int32)
+    cw = rng.integers(0, 7, 50).astype(np.int32)
+    a = H.gather_normalize(grid, ch, cw, tree=True).astype(np.float32)
+    b = H.gather_normalize(grid, ch, cw, tree=False).astype(np.float32)
+    assert np.abs(a - b).max() <= 2.0 ** -10
+    np.testing.assert_allclose(np.linalg.norm(a, axis=1), 1.0, atol=2e-3)
+
+
+def test_hostpath_known_answers(golden_dir):
+    m = _meta(golden_dir)
+    nk = m["normalize_kpts"]
+    out = H.normalize_kpts(np.array(nk["kp"], np.float32), nk["image_w"], nk["image_h"])
+    np.testing.assert_array_equal(out, np.array(nk["expected"], np.float32))
+    # hand-computed: (0,0) -> (-(1241/2)/(1241/2), -(376/2)/(1241/2)) ; centre -> (0,0)
+    np.testing.assert_allclose(out[0], [-1.0, -188.0 / 620.5], rtol=1e-6)
+    np.testing.assert_allclose(out[1], [0.0, 0.0], atol=1e-7)
+    fm = m["filter_matches"]
+    q, t, d = H.filter_matches(np.array(fm["matches0"], np.int32), np.array(fm["mscores0"], np.float32))
+    assert q.tolist() == fm["query"] == [0, 2, 4, 5]
+    assert t.tolist() == fm["train"] == [3, 0, 7, 2]
+    np.testing.assert_allclose(d, [0.1, 0.75, 0.0, 0.875], atol=1e-7)
+
+
+def test_half_conversions_round_trip():
+    rng = np.random.default_rng(7)
+    f = np.concatenate([rng.standard_normal(4096).astype(np.float32) * 10, [0, -0.0, 65504, 1e-7, 6e-8, 70000, -70000]])
+    f = f.astype(np.float32)
+    np.testing.assert_array_equal(H.float_to_half(f).view(np.uint16), f.astype(np.float16).view(np.uint16))
+    h = np.arange(0, 0x7c00, 7, dtype=np.uint16).view(np.float16)
+    np.testing.assert_array_equal(H.half_to_float(h), h.astype(np.float32))
+
+
+def test_lightglue_selfcheck_vectors(golden_dir):
+    """Self-consistency only (parity unpinned, see oracle/lightglue_ref.py): fp64 regenerates the vectors,
+    fp32 agrees with fp64 on every decision."""
+    lg = make_lightglue_weights(1)
+    g = np.load(os.path.join(golden_dir, "lightglue_selfcheck.npz"))
+    for tag in ("n7x5", "n64x64", "n97x130"):
+        k0, k1 = torch.from_numpy(g[tag + "_kpts0"])[None], torch.from_numpy(g[tag + "_kpts1"])[None]
+        d0 = torch.from_numpy(g[tag + "_desc0"].astype(np.float32))[None]
+        d1 = torch.from_numpy(g[tag + "_desc1"].astype(np.float32))[None]
+        with torch.no_grad():
+            m64, s64 = L.match(lg, k0, d0, k1, d1)
+            m32, s32 = L.match(lg, k0, d0, k1, d1, dtype=torch.float32)
+        np.testing.assert_array_equal(m64[0].numpy(), g[tag + "_matches0"])
+        np.testing.assert_allclose(s64[0].numpy(), g[tag + "_mscores0"], atol=1e-6)
+        assert (m32 == m64).float().mean() >= 0.99
+        np.testing.assert_allclose(s32[0].numpy(), s64[0].numpy(), atol=2e-3)
+        assert (g[tag + "_matches0"] >= 0).sum() > 0   # the vectors exercise real matches, not only -1
+
+
+def test_lightglue_tiny_assignment_by_hand():
+    """N0 = N1 = 3 hand-checkable assignment/filter stage (filter_matches + sigmoid_log_double_softmax)."""
+    sim = torch.tensor([[[10.0, 0.0, 0.0], [0.0, 10.0, 0.0], [0.0, 9.0, 1.0]]], dtype=torch.float64)
+    z = torch.full((1, 3, 1), 20.0, dtype=torch.float64)  # logsigmoid(20) ~ -2e-9
+    cert = torch.nn.functional.logsigmoid(z) + torch.nn.functional.logsigmoid(z).transpose(1, 2)
+    scores = torch.log_softmax(sim, 2) + torch.log_softmax(sim, 1) + cert
+    m0, ms0 = L.filter_matches(scores)
+    assert m0[0].tolist() == [0, 1, -1]          # row 2's best column (1) prefers row 1 -> not mutual
+    assert ms0[0, 2].item() == 0.0
+    assert ms0[0, 0].item() > 0.99

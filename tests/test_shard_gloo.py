@@ -1,0 +1,65 @@
+"""CPU: the N>1 path (sharding + the one all-gather) on world_size-2 gloo."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from superslam_amd.shard import all_gather_features, pair_schedule, shard_block, shard_round_robin
+
+
+def _fake(unit, k=6):
+    g = torch.Generator().manual_seed(1000 + unit)
+    n = int(torch.randint(0, k + 1, (1,), generator=g))
+    desc = torch.zeros((k, 256), dtype=torch.float16)
+    desc[:n] = torch.randn((n, 256), generator=g).half()
+    kp = torch.zeros((k, 3))
+    kp[:n] = torch.rand((n, 3), generator=g)
+    return desc, kp, n
+
+
+def _worker(rank, world, total, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard_block(total, rank, world)
+    local = [_fake(u) for u in range(a, b)]
+    desc = torch.stack([x[0] for x in local]) if local else torch.zeros((0, 6, 256), dtype=torch.float16)
+    kp = torch.stack([x[1] for x in local]) if local else torch.zeros((0, 6, 3))
+    n = torch.tensor([x[2] for x in local], dtype=torch.int32)
+    gd, gk, gn = all_gather_features(desc, kp, n, total)
+    ok = True
+    for u in range(total):
+        d, k, nn = _fake(u)
+        ok &= bool(torch.equal(gd[u], d) and torch.equal(gk[u], k) and int(gn[u]) == nn)
+    q.put((rank, ok, tuple(gd.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [7, 8])
+def test_all_gather_equals_single_process_concatenation(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + total
+    procs = [ctx.Process(target=_worker, args=(r, 2, total, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (total, 6, 256) for _, _, shape in res)
+
+
+def test_sharding_covers_every_unit_once():
+    for total in (0, 1, 7, 8, 4096):
+        for world in (1, 2, 4, 8):
+            blocks = [shard_block(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            rr = sorted(u for r in range(world) for u in shard_round_robin(total, r, world))
+            assert rr == list(range(total))
+    sched = pair_schedule(8, 8)
+    flat = sorted(p for r in sched for p in r)
+    assert len(flat) == 28 and len(set(flat)) == 28 and max(len(r) for r in sched) - min(len(r) for r in sched) <= 1
