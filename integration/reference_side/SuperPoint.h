@@ -1,0 +1,78 @@
+// Reference-side binding (goes into the SuperSLAM tree as include/SuperPoint.h; replaces the TensorRT runner).
+// Same class name, constructor and methods as the reference's header (include/SuperPoint.h:36-54), so
+// SuperSLAM.cc:68-87, StereoFrontEnd, RgbdFrontEnd and VoEstimator compile and run unchanged.  All work is
+// forwarded to libsuperslam_hip.so through include/superslam_hip/frontend.hpp -> include/sship.h.
+// Needs OpenCV (as the reference does); not built in this repository's image (no OpenCV here) - the OpenCV-free
+// layer it wraps is built and tested in tests/cpp/.
+#ifndef SUPERPOINT_HIP_ADAPTER_H_
+#define SUPERPOINT_HIP_ADAPTER_H_
+
+#include <memory>
+#include <opencv4/opencv2/opencv.hpp>
+#include <string>
+#include <vector>
+
+#include "DescriptorPool.h"       // the reference's own header (unchanged): superslam::DeviceDescriptors
+#include "InferenceInterfaces.h"  // the reference's own header (unchanged): IFeatureExtractor, Features
+#include "Logging.h"
+#include "Profiling.h"
+#include "superslam_hip/frontend.hpp"
+
+namespace superslam_hip_adapter {
+inline superslam_hip::Image as_image(const cv::Mat& m, cv::Mat& keep) {
+  keep = m.isContinuous() ? m : m.clone();
+  if (keep.depth() != CV_8U) keep.convertTo(keep, CV_8U);
+  return superslam_hip::Image{keep.data, keep.rows, keep.cols, keep.channels(), static_cast<int>(keep.step)};
+}
+inline void to_cv(const std::vector<superslam_hip::KeyPoint>& in, std::vector<cv::KeyPoint>& out) {
+  out.clear();
+  out.reserve(in.size());
+  for (const auto& k : in) out.emplace_back(k.x, k.y, k.size, k.angle, k.response);
+}
+inline superslam::DeviceDescriptors to_ref(const superslam_hip::DeviceDescriptors& d) {
+  superslam::DeviceDescriptors o;
+  o.data = d.data; o.count = d.count; o.dim = d.dim; o.slot = d.slot; o.slot_ref = d.slot_ref;
+  return o;
+}
+inline superslam::Features to_ref(superslam_hip::Features&& f) {
+  superslam::Features o;
+  to_cv(f.keypoints, o.keypoints);
+  o.descriptors = to_ref(f.descriptors);
+  return o;
+}
+}  // namespace superslam_hip_adapter
+
+class SuperPoint : public superslam::IFeatureExtractor {
+public:
+  explicit SuperPoint(const std::string& engine_file, int max_keypoints, double keypoint_threshold, int remove_borders)
+      : impl_(engine_file, max_keypoints, keypoint_threshold, remove_borders) {}
+  bool initialize() {
+    const bool ok = impl_.initialize();
+    if (!ok) SLOG_ERROR("SuperPoint(HIP): {}", impl_.last_error());
+    return ok;
+  }
+  bool infer(const cv::Mat& image, std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors) {
+    cv::Mat keep;
+    std::vector<superslam_hip::KeyPoint> kp;
+    superslam_hip::HostDescriptors d;
+    if (!impl_.infer(superslam_hip_adapter::as_image(image, keep), kp, d)) return false;
+    superslam_hip_adapter::to_cv(kp, keypoints);
+    descriptors = d.rows ? cv::Mat(d.rows, d.cols, CV_32F, d.data.data()).clone() : cv::Mat();
+    return true;
+  }
+  superslam::Features extract(const cv::Mat& image) override {
+    cv::Mat keep;
+    return superslam_hip_adapter::to_ref(impl_.extract(superslam_hip_adapter::as_image(image, keep)));
+  }
+  std::pair<superslam::Features, superslam::Features> extract_stereo(const cv::Mat& left, const cv::Mat& right) override {
+    SUPERSLAM_PROFILE_SCOPE("sp_extract_stereo");
+    cv::Mat kl, kr;
+    auto lr = impl_.extract_stereo(superslam_hip_adapter::as_image(left, kl), superslam_hip_adapter::as_image(right, kr));
+    return {superslam_hip_adapter::to_ref(std::move(lr.first)), superslam_hip_adapter::to_ref(std::move(lr.second))};
+  }
+
+private:
+  superslam_hip::SuperPoint impl_;
+};
+typedef std::shared_ptr<SuperPoint> SuperPointPtr;
+#endif

@@ -93,11 +93,11 @@ class LightGlue:
         r = MatchResult()
         if self._h is None:
             return r
-        k0 = np.ascontiguousarray(kp0, np.float32).reshape(len(kp0), -1)
-        k1 = np.ascontiguousarray(kp1, np.float32).reshape(len(kp1), -1)
-        n0, n1 = k0.shape[0], k1.shape[0]
+        n0, n1 = len(kp0), len(kp1)
         if n0 == 0 or n1 == 0:
             return r
+        k0 = np.ascontiguousarray(kp0, np.float32).reshape(n0, -1)
+        k1 = np.ascontiguousarray(kp1, np.float32).reshape(n1, -1)
         m0 = np.full(n0, -1, np.int32)
         ms0 = np.zeros(n0, np.float32)
         L = _lib.lib()

@@ -1,0 +1,130 @@
+// C++ host-layer tests.  CPU part: FreeList semantics (the reference's tests/test_descriptor_pool.cc cases)
+// and "fails loudly without a device".  GPU part (argv[1] = sp weights, argv[2] = lg weights): the
+// StereoFrontEnd consumer semantics of the reference's tests/test_stereo_frontend.cc, driven through the real
+// extractor / matcher behind the IFeatureExtractor / IFeatureMatcher interfaces.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "superslam_hip/frontend.hpp"
+
+using namespace superslam_hip;
+
+static int g_fail = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
+
+static void test_freelist() {
+  {  // FreeList.AcquireReleaseRoundTrips
+    FreeList f(3);
+    const int a = f.acquire(), b = f.acquire(), c = f.acquire();
+    EXPECT(a >= 0); EXPECT(b >= 0); EXPECT(c >= 0);
+    EXPECT(f.acquire() == -1);
+    EXPECT(f.in_use() == 3);
+    f.release(b);
+    EXPECT(f.in_use() == 2);
+    EXPECT(f.acquire() == b);
+  }
+  {  // FreeList.EmptyAndFull
+    FreeList f(2);
+    EXPECT(f.in_use() == 0);
+    const int a = f.acquire(), b = f.acquire();
+    EXPECT(f.in_use() == 2);
+    f.release(a); f.release(b);
+    EXPECT(f.in_use() == 0);
+  }
+}
+
+// procedural frame (value noise is overkill here: blocks + gradients give SuperPoint plenty of corners)
+static std::vector<uint8_t> make_image(int h, int w, int shift) {
+  std::vector<uint8_t> img(static_cast<size_t>(h) * w);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int xs = x + shift;
+      unsigned v = ((xs / 13) * 37 + (y / 11) * 91) & 0xff;
+      v = (v * 3 + ((xs * 5 + y * 3) & 31) * 2) & 0xff;
+      img[static_cast<size_t>(y) * w + x] = static_cast<uint8_t>(v);
+    }
+  return img;
+}
+
+static int run_gpu(const char* spw, const char* lgw) {
+  const int H = 240, W = 320;
+  SuperPoint sp(spw, 300, 0.005, 4);
+  EXPECT(sp.initialize());
+  LightGlue lg(lgw, W, H, 300);
+  EXPECT(lg.initialize());
+  LightGlue lg2(lg.shared_engine(), W, H, 300);  // second matcher on the shared weights (loop-closure thread)
+  EXPECT(lg2.initialize());
+  if (g_fail) return 1;
+  const auto left = make_image(H, W, 0), right = make_image(H, W, 10);  // right = left shifted by 10 px
+  Image L{left.data(), H, W, 1, 0}, R{right.data(), H, W, 1, 0};
+  IFeatureExtractor* ext = &sp;
+  IFeatureMatcher* matcher = &lg;
+  auto lr = ext->extract_stereo(L, R);
+  EXPECT(!lr.first.keypoints.empty());
+  EXPECT(lr.first.descriptors.count == static_cast<int>(lr.first.keypoints.size()));
+  EXPECT(sp.pool_in_use() == 2);
+  MatchResult m = matcher->match(lr.first.keypoints, lr.first.descriptors, lr.second.keypoints, lr.second.descriptors);
+  // StereoFrontEnd::process gates (src/StereoFrontEnd.cc:35-48)
+  int with_depth = 0, disparity10 = 0, ascending = 1, last = -1;
+  for (const DMatch& d : m.matches) {
+    if (d.queryIdx <= last) ascending = 0;
+    last = d.queryIdx;
+    const KeyPoint& a = lr.first.keypoints[d.queryIdx];
+    const KeyPoint& b = lr.second.keypoints[d.trainIdx];
+    if (a.x - b.x < 1.0f) continue;
+    if (std::fabs(a.y - b.y) > 2.0f) continue;
+    ++with_depth;
+    if (std::fabs((a.x - b.x) - 10.0f) < 0.5f) ++disparity10;
+  }
+  std::printf("cpp: %zu/%zu keypoints, %zu matches, %d with depth, %d at disparity 10\n", lr.first.keypoints.size(),
+              lr.second.keypoints.size(), m.matches.size(), with_depth, disparity10);
+  EXPECT(ascending);
+  EXPECT(with_depth > 0);
+  EXPECT(disparity10 * 10 >= with_depth * 8);  // the synthetic pair has a constant 10 px disparity
+  // zero disparity: left == right -> every gated match is rejected (MarksBelowFloorDisparityAsNoDepth)
+  auto ll = ext->extract_stereo(L, L);
+  MatchResult mz = matcher->match(ll.first.keypoints, ll.first.descriptors, ll.second.keypoints, ll.second.descriptors);
+  int below = 0;
+  for (const DMatch& d : mz.matches) if (ll.first.keypoints[d.queryIdx].x - ll.second.keypoints[d.trainIdx].x < 1.0f) ++below;
+  EXPECT(!mz.matches.empty() && below == static_cast<int>(mz.matches.size()));
+  // host-descriptor overload through the second matcher == device overload
+  HostDescriptors h0 = lg.descriptors_to_host(lr.first.descriptors), h1 = lg.descriptors_to_host(lr.second.descriptors);
+  EXPECT(h0.rows == static_cast<int>(lr.first.keypoints.size()) && h0.cols == 256);
+  MatchResult mh = lg2.match(lr.first.keypoints, h0, lr.second.keypoints, h1);
+  EXPECT(mh.matches.size() == m.matches.size());
+  for (size_t i = 0; i < std::min(mh.matches.size(), m.matches.size()); ++i) EXPECT(mh.matches[i].trainIdx == m.matches[i].trainIdx);
+  // empty inputs never throw: empty results
+  std::vector<KeyPoint> none;
+  EXPECT(matcher->match(none, DeviceDescriptors(), lr.second.keypoints, lr.second.descriptors).matches.empty());
+  EXPECT(lg.descriptors_to_host(DeviceDescriptors()).empty());
+  MatchResult r5;
+  EXPECT(!lg.match(none, HostDescriptors(), none, HostDescriptors(), r5));
+  // pool exhaustion (8 slots): handles held -> the 5th stereo call fails softly and frees nothing it does not own
+  std::vector<std::pair<Features, Features>> held;
+  for (int i = 0; i < 3; ++i) held.push_back(ext->extract_stereo(L, R));  // 2 + 2 (ll) + 6 = 10 > 8
+  EXPECT(sp.pool_in_use() == 8);
+  EXPECT(held.back().second.descriptors.empty() || held.back().first.descriptors.empty());
+  held.clear(); ll = {}; lr = {};
+  EXPECT(sp.pool_in_use() == 0);
+  return g_fail ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  test_freelist();
+  if (argc < 3) {
+    // CPU box: the library must fail loudly, never fall back
+    if (sship_init(-1) == SSHIP_OK) { std::printf("cpp: a GPU is visible, pass weight paths to run the GPU part\n"); return g_fail ? 1 : 0; }
+    SuperPoint sp("missing.safetensors", 600, 0.005, 4);
+    EXPECT(!sp.initialize());
+    EXPECT(sp.last_error().find("no HIP device") != std::string::npos);
+    Features f = sp.extract(Image{});
+    EXPECT(f.keypoints.empty() && f.descriptors.empty());
+    std::printf("cpp: host-layer CPU checks %s\n", g_fail ? "FAILED" : "ok");
+    return g_fail ? 1 : 0;
+  }
+  const int rc = run_gpu(argv[1], argv[2]);
+  std::printf("cpp: host-layer GPU checks %s\n", rc ? "FAILED" : "ok");
+  return rc;
+}

@@ -200,7 +200,7 @@ def test_superpoint_dense_vs_reference_vectors(sp, weights_dir, golden_dir, name
     d_d32 = _stats(f"{name} desc vs reference (fp32)", desc, g["descriptors"].astype(np.float32))
     cos = (desc * g["descriptors"].astype(np.float32)).sum(0)
     print(f"{name} desc cosine vs reference: min {cos.min():.6f}")
-    assert d_l16.max() < 2e-2 and d_l32.max() < 0.15     # logits are O(10); fp16 activations
+    assert d_l16.max() < 4e-2 and d_l32.max() < 0.15     # logits are O(25): 4e-2 is ~3 fp16 ulp of the activations
     assert d_d16.max() < 1.5e-3 and d_d32.max() < 2e-3 and cos.min() > 0.9995
     # scores: NMS'd heatmap; compare where both agree on survival, and count survival flips
     both = (scores > 0) & (g["scores"] > 0)
@@ -249,7 +249,7 @@ def test_superpoint_extract_vs_oracle_end_to_end(sp, weights_dir):
         assert len(f.keypoints) == 600 and iou > 0.9
         sc = f.keypoints[:, 2]
         assert (np.diff(sc) <= 0).all()      # sortedness property (descending response)
-    del fl, fr
+    del fl, fr, f
     import gc; gc.collect()
     assert sp.pool_in_use() == 0            # handles returned their slots
 
