@@ -43,6 +43,25 @@ def lg_flops_per_pair(n):
     return 2.0 * mac
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask and cgroup CPU quota, not the machine's core count
+    (oversubscribed OpenMP teams spin and make the CPU leg take minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(spw, lgw, left, right, max_kp, budget_s=20.0):
     """The CPU oracle on the host cores: same synthetic pair, fp32, all cores."""
     import numpy as np
@@ -52,7 +71,7 @@ def cpu_baseline(spw, lgw, left, right, max_kp, budget_s=20.0):
     from oracle import lightglue_ref as LR
     from oracle import superpoint_ref as R
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
 
     def one_pair():
@@ -85,6 +104,9 @@ def cpu_baseline(spw, lgw, left, right, max_kp, budget_s=20.0):
 
 
 def main():
+    import faulthandler
+
+    faulthandler.dump_traceback_later(int(os.environ.get("BENCH_WATCHDOG_S", "900")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)

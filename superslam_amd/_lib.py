@@ -83,6 +83,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SshipError(ERR_IO, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                      "(hipcc --offload-arch=gfx950); there is no fallback path")
+        # ONE HIP runtime per process: torch bundles its own libamdhip64 / libhsa-runtime64, and a second
+        # copy (the system one this library was linked against) cannot initialise the GPU once the first has.
+        # Importing torch first makes the dynamic loader resolve our DT_NEEDED libamdhip64.so.7 to the copy
+        # torch already mapped (same SONAME), exactly like a torch.utils.cpp_extension module.
+        import torch  # noqa: F401  (device-memory / stream plumbing only)
+
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
