@@ -776,8 +776,8 @@ constexpr int kLgLayers = 9;
 struct sship_lg_weights {
   std::mutex mu;
   int refs = 1;
-  ConvW qkv[kLgLayers], outp[kLgLayers], ffn0_s[kLgLayers], ffn3_s[kLgLayers];
-  ConvW cqkv[kLgLayers], to_out[kLgLayers], ffn0_c[kLgLayers], ffn3_c[kLgLayers];
+  ConvW qkv[kLgLayers], ffn0_s[kLgLayers], ffn3_s[kLgLayers];  // ffn0_*: out_proj / to_out folded in
+  ConvW cqkv[kLgLayers], ffn0_c[kLgLayers], ffn3_c[kLgLayers];
   float *ln_g_s[kLgLayers] = {}, *ln_b_s[kLgLayers] = {}, *ln_g_c[kLgLayers] = {}, *ln_b_c[kLgLayers] = {};
   ConvW final_proj;
   float* match_w = nullptr;
@@ -786,7 +786,7 @@ struct sship_lg_weights {
 };
 static void lg_weights_free(sship_lg_weights* w) {
   for (int i = 0; i < kLgLayers; ++i) {
-    for (ConvW* c : {&w->qkv[i], &w->outp[i], &w->ffn0_s[i], &w->ffn3_s[i], &w->cqkv[i], &w->to_out[i], &w->ffn0_c[i], &w->ffn3_c[i]})
+    for (ConvW* c : {&w->qkv[i], &w->ffn0_s[i], &w->ffn3_s[i], &w->cqkv[i], &w->ffn0_c[i], &w->ffn3_c[i]})
       free_conv(*c);
     for (float* p : {w->ln_g_s[i], w->ln_b_s[i], w->ln_g_c[i], w->ln_b_c[i]}) if (p) (void)hipFree(p);
   }
@@ -808,7 +808,35 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     const Tensor* wt = find_tensor(sd, name + ".weight", {cout, cin}, err);
     const Tensor* bs = wt ? find_tensor(sd, name + ".bias", {cout}, err) : nullptr;
     if (!wt || !bs) return SSHIP_ERR_IO;
-    return upload_conv(wt->data.data(), bs->data.data(), cout, cin, 1, 128, dst, map, scale);
+    // 256-row layers use 64-row workgroup tiles (more workgroups for the small token GEMMs), wider ones 128.
+    return upload_conv(wt->data.data(), bs->data.data(), cout, cin, 1, cout <= 256 ? 64 : 128, dst, map, scale);
+  };
+  // FFN of a block with the attention output projection folded into ffn.0:
+  //   ffn.0(cat[x, Wo c + bo]) = cat[x, c] [W0a | W0b Wo]^T + (b0 + W0b bo)      (fp64 accumulate on the host)
+  // ffn.0' is packed in 64-row blocks and ffn.3 in 32-row blocks: one block per wave of k_lg_ffn.
+  auto ffn = [&](const std::string& p, const char* proj, ConvW& d0, ConvW& d3) -> int {
+    const Tensor* wo = find_tensor(sd, p + proj + ".weight", {256, 256}, err);
+    const Tensor* bo = wo ? find_tensor(sd, p + proj + ".bias", {256}, err) : nullptr;
+    const Tensor* w0 = bo ? find_tensor(sd, p + "ffn.0.weight", {512, 512}, err) : nullptr;
+    const Tensor* b0 = w0 ? find_tensor(sd, p + "ffn.0.bias", {512}, err) : nullptr;
+    const Tensor* w3 = b0 ? find_tensor(sd, p + "ffn.3.weight", {256, 512}, err) : nullptr;
+    const Tensor* b3 = w3 ? find_tensor(sd, p + "ffn.3.bias", {256}, err) : nullptr;
+    if (!b3) return SSHIP_ERR_IO;
+    std::vector<float> wf(512 * 512), bf(512);
+    for (int o = 0; o < 512; ++o) {
+      const float* row = w0->data.data() + (size_t)o * 512;
+      for (int i = 0; i < 256; ++i) wf[(size_t)o * 512 + i] = row[i];
+      double bacc = b0->data[o];
+      for (int k = 0; k < 256; ++k) bacc += (double)row[256 + k] * bo->data[k];
+      bf[o] = (float)bacc;
+      for (int i = 0; i < 256; ++i) {
+        double a = 0.0;
+        for (int k = 0; k < 256; ++k) a += (double)row[256 + k] * wo->data[(size_t)k * 256 + i];
+        wf[(size_t)o * 512 + 256 + i] = (float)a;
+      }
+    }
+    if (int rc = upload_conv(wf.data(), bf.data(), 512, 512, 1, 64, d0)) return rc;
+    return upload_conv(w3->data.data(), b3->data.data(), 256, 512, 1, 32, d3);
   };
   auto vec = [&](const std::string& name, int n, float** dst) -> int {
     const Tensor* t = find_tensor(sd, name, {n}, err);
@@ -834,9 +862,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     const std::string pc = "transformers." + std::to_string(i) + ".cross_attn.";
     int rc = 0;
     if ((rc = lin(ps + "Wqkv", 768, 256, w->qkv[i], &qkv_map, &qkv_scale))) return bail(rc, err);
-    if ((rc = lin(ps + "out_proj", 256, 256, w->outp[i]))) return bail(rc, err);
-    if ((rc = lin(ps + "ffn.0", 512, 512, w->ffn0_s[i]))) return bail(rc, err);
-    if ((rc = lin(ps + "ffn.3", 256, 512, w->ffn3_s[i]))) return bail(rc, err);
+    if ((rc = ffn(ps, "out_proj", w->ffn0_s[i], w->ffn3_s[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(ps + "ffn.1.weight", 512, &w->ln_g_s[i]))) return bail(rc, err);
     if ((rc = vec(ps + "ffn.1.bias", 512, &w->ln_b_s[i]))) return bail(rc, err);
     // fused [to_qk ; to_v] -> one 512-row GEMM
@@ -852,9 +878,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     memcpy(bcat.data() + 256, bv->data.data(), 256 * 4);
     for (int r = 0; r < 256; ++r) scat[r] = cq_scale[r];
     if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 128, w->cqkv[i], nullptr, &scat))) return bail(rc, g_err);
-    if ((rc = lin(pc + "to_out", 256, 256, w->to_out[i]))) return bail(rc, err);
-    if ((rc = lin(pc + "ffn.0", 512, 512, w->ffn0_c[i]))) return bail(rc, err);
-    if ((rc = lin(pc + "ffn.3", 256, 512, w->ffn3_c[i]))) return bail(rc, err);
+    if ((rc = ffn(pc, "to_out", w->ffn0_c[i], w->ffn3_c[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(pc + "ffn.1.weight", 512, &w->ln_g_c[i]))) return bail(rc, err);
     if ((rc = vec(pc + "ffn.1.bias", 512, &w->ln_b_c[i]))) return bail(rc, err);
   }
@@ -891,7 +915,7 @@ struct sship_lg {
   sship_lg_weights* w = nullptr;
   int image_w = 0, image_h = 0, max_kp = 0, max_pairs = 0, NP = 0;
   hipStream_t stream = nullptr;
-  DevBuf x, rope, q, k, vt, ctx, msg, h1, md, logsig, sim, ws;
+  DevBuf x, rope, q, k, vt, ctx, md, logsig, sim, ws;
   DevBuf kp_stage, desc_stage, lens, m0, ms0;
   PinBuf h_kp, h_lens, h_m0, h_ms0, h_desc;
 };
@@ -911,8 +935,6 @@ extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, in
   SSHIP_HIP_CHECK(lg->k.ensure(T * 256 * 2));
   SSHIP_HIP_CHECK(lg->vt.ensure(T * 256 * 2));
   SSHIP_HIP_CHECK(lg->ctx.ensure(T * 256 * 2));
-  SSHIP_HIP_CHECK(lg->msg.ensure(T * 256 * 2));
-  SSHIP_HIP_CHECK(lg->h1.ensure(T * 512 * 2));
   SSHIP_HIP_CHECK(lg->md.ensure(T * 256 * 2));
   SSHIP_HIP_CHECK(lg->logsig.ensure(T * 4));
   SSHIP_HIP_CHECK(lg->sim.ensure((size_t)max_pairs * NP * NP * 4));
@@ -964,7 +986,7 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   LgDims d{2 * pairs, lg->NP};
   const int T = d.S * d.NP;
   _Float16 *x = lg->x.as<_Float16>(), *q = lg->q.as<_Float16>(), *k = lg->k.as<_Float16>(), *vt = lg->vt.as<_Float16>();
-  _Float16 *ctx = lg->ctx.as<_Float16>(), *msg = lg->msg.as<_Float16>(), *h1 = lg->h1.as<_Float16>();
+  _Float16* ctx = lg->ctx.as<_Float16>();
   float* rope = lg->rope.as<float>();
   launch_lg_prep(kp, kp_stride, kp_seq_stride, lens, desc, desc_seq_stride, w->wr, (float)lg->image_w,
                  (float)lg->image_h, d, x, rope, s);
@@ -972,17 +994,11 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
     // SelfBlock (both images of every pair in one launch)
     SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[i], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
     launch_lg_attention(q, k, vt, lens, d, false, ctx, s);
-    SSHIP_HIP_CHECK(lg_linear_f16(w->outp[i], ctx, 256, nullptr, 0, d, msg, 256, s));
-    SSHIP_HIP_CHECK(lg_linear_f16(w->ffn0_s[i], x, 256, msg, 256, d, h1, 512, s));
-    launch_lg_ln_gelu(h1, w->ln_g_s[i], w->ln_b_s[i], T, s);
-    SSHIP_HIP_CHECK(lg_linear_resid(w->ffn3_s[i], h1, 512, d, x, s));
+    launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], ctx, x, T, s);
     // CrossBlock (qk shared by both directions; sequence s attends to s^1)
     SSHIP_HIP_CHECK(lg_linear_heads(w->cqkv[i], x, d, /*rope_segs=*/0, /*t_seg=*/1, rope, q, k, vt, s));
     launch_lg_attention(q, q, vt, lens, d, true, ctx, s);
-    SSHIP_HIP_CHECK(lg_linear_f16(w->to_out[i], ctx, 256, nullptr, 0, d, msg, 256, s));
-    SSHIP_HIP_CHECK(lg_linear_f16(w->ffn0_c[i], x, 256, msg, 256, d, h1, 512, s));
-    launch_lg_ln_gelu(h1, w->ln_g_c[i], w->ln_b_c[i], T, s);
-    SSHIP_HIP_CHECK(lg_linear_resid(w->ffn3_c[i], h1, 512, d, x, s));
+    launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], ctx, x, T, s);
   }
   SSHIP_HIP_CHECK(lg_linear_f16(w->final_proj, x, 256, nullptr, 0, d, lg->md.as<_Float16>(), 256, s));
   launch_lg_matchability(x, w->match_w, w->match_b, T, lg->logsig.as<float>(), s);

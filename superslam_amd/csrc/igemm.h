@@ -49,7 +49,10 @@ template <int KS, int CIN, int CT, int TH, class Epi>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   constexpr int HALO = KS / 2, TW = 32, TWH = TW + KS - 1, THH = TH + KS - 1;
   constexpr int MT = CT / 32, NT = TH / 4, NCHUNK = CIN / 64;
-  constexpr int WSTAGE = KS * 4 * MT * 512;  // halfs per weight stage
+  constexpr int WSTAGE = KS * 4 * MT * 512;  // halfs per weight stage (one tap row of one 64-channel chunk)
+  constexpr int NSTAGE = NCHUNK * KS;
+  constexpr int IN_UNITS = THH * TWH * 8, IN_IT = (IN_UNITS + 255) / 256;  // 16-byte units
+  constexpr int W_UNITS = WSTAGE / 8, W_IT = (W_UNITS + 255) / 256;
   static_assert(TH % 4 == 0 && CT % 32 == 0 && CIN % 64 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   _Float16* s_in = reinterpret_cast<_Float16*>(smem);
@@ -74,44 +77,77 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 
   const _Float16* wbase = p.wpack + (size_t)cb * (NCHUNK * KS * WSTAGE);
 
-  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+  // Software pipeline: the global loads of stage s+1 (weights; the input tile when a new 64-channel chunk
+  // starts) are issued into registers BEFORE the MFMAs of stage s and written to LDS after them, so HBM/L2
+  // latency hides under the matrix work instead of being exposed once per stage.
+  uint4 rin[IN_IT], rw[W_IT];
+  auto load_in = [&](int chunk) {
     const int c0 = chunk * 64;
     const _Float16* src;
     int cs;
     if (c0 < p.cin0) { src = p.in0 + c0; cs = p.cs0; } else { src = p.in1 + (c0 - p.cin0); cs = p.cs1; }
-    __syncthreads();  // everyone is done with the previous chunk's tiles
-    // ---- stage the input tile (zero-filled halo / overhang), 16 B per thread per step, coalesced ----
-    for (int u = tid; u < THH * TWH * 8; u += 256) {
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int u = tid + i * 256;
       const int pix = u >> 3, part = u & 7;
       const int py = pix / TWH, px = pix - py * TWH;
       const int gy = y0 - HALO + py, gx = x0 - HALO + px;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+      if (u < IN_UNITS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
         v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * cs + part * 8);
-      *reinterpret_cast<uint4*>(s_in + pix * kCP + part * 8) = v;
+      rin[i] = v;
     }
+  };
+  auto store_in = [&]() {
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int u = tid + i * 256;
+      if (u < IN_UNITS) *reinterpret_cast<uint4*>(s_in + (u >> 3) * kCP + (u & 7) * 8) = rin[i];
+    }
+  };
+  auto load_w = [&](int stage) {
+    const _Float16* wsrc = wbase + (size_t)stage * WSTAGE;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + i * 256;
+      if (W_UNITS % 256 == 0 || u < W_UNITS) rw[i] = *reinterpret_cast<const uint4*>(wsrc + u * 8);
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + i * 256;
+      if (W_UNITS % 256 == 0 || u < W_UNITS) *reinterpret_cast<uint4*>(s_w + u * 8) = rw[i];
+    }
+  };
+
+  load_in(0);
+  load_w(0);
 #pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky) {
-      if (ky > 0) __syncthreads();  // previous tap row's weight reads are done
-      const _Float16* wsrc = wbase + (size_t)(chunk * KS + ky) * WSTAGE;
-      for (int u = tid; u < WSTAGE / 8; u += 256)
-        *reinterpret_cast<uint4*>(s_w + u * 8) = *reinterpret_cast<const uint4*>(wsrc + u * 8);
-      __syncthreads();
+  for (int s = 0; s < NSTAGE; ++s) {
+    const int ky = s % KS;
+    __syncthreads();  // every wave is done reading the previous stage's tiles
+    if (ky == 0) store_in();
+    store_w();
+    __syncthreads();
+    if (s + 1 < NSTAGE) {
+      if ((s + 1) % KS == 0) load_in((s + 1) / KS);
+      load_w(s + 1);
+    }
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
+    for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          h8_t a[MT];
+      for (int ks = 0; ks < 4; ++ks) {
+        h8_t a[MT];
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            a[m] = *reinterpret_cast<const h8_t*>(s_w + ((kx * 4 + ks) * MT + m) * 512 + lane * 8);
+        for (int m = 0; m < MT; ++m)
+          a[m] = *reinterpret_cast<const h8_t*>(s_w + ((kx * 4 + ks) * MT + m) * 512 + lane * 8);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const int row = wave * NT + n + ky;
-            const h8_t bf = *reinterpret_cast<const h8_t*>(s_in + (row * TWH + j + kx) * kCP + ks * 16 + hh * 8);
+        for (int n = 0; n < NT; ++n) {
+          const int row = wave * NT + n + ky;
+          const h8_t bf = *reinterpret_cast<const h8_t*>(s_in + (row * TWH + j + kx) * kCP + ks * 16 + hh * 8);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(a[m], bf, acc[m][n]);
-          }
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(a[m], bf, acc[m][n]);
         }
       }
     }

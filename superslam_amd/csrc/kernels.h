@@ -80,7 +80,8 @@ hipError_t lg_linear_f16(const ConvW& w, const _Float16* in0, int cs0, const _Fl
 hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d, _Float16* x, hipStream_t s);
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,
                          bool cross, _Float16* ctx, hipStream_t s);
-void launch_lg_ln_gelu(_Float16* h, const float* gamma, const float* beta, int tokens, hipStream_t s);
+void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
+                   _Float16* x, int tokens, hipStream_t s);
 void launch_lg_matchability(const _Float16* x, const float* w, float bias, int tokens, float* logsig, hipStream_t s);
 void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s);
 void launch_lg_assign(const float* sim, const float* logsig, const int* lens, LgDims d, float* ws, int max_kp,

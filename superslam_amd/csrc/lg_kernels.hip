@@ -83,12 +83,20 @@ struct EpiHeads {
             const float r2 = v2 * cs.z - v3 * cs.w, r3 = v3 * cs.z + v2 * cs.w;
             v0 = r0; v1 = r1; v2 = r2; v3 = r3;
           }
+          const int nt32 = NP >> 5, kt = tn >> 5, kap = tn & 31;
+          const size_t tile = ((size_t)s * 4 + hd) * nt32 + kt;
           if (seg != t_seg) {
+            // Q / K: MFMA-fragment order per 32-token tile: [tile][kstep d/16][lane = ((d%16)/8)*32 + token%32][d%8]
             _Float16* dst = static_cast<_Float16*>(seg == 0 ? p.out0 : p.out1);
-            *reinterpret_cast<h4_t*>(dst + (((size_t)s * 4 + hd) * NP + tn) * 64 + d0) = to_h4(v0, v1, v2, v3);
+            *reinterpret_cast<h4_t*>(dst + (tile * 4 + (d0 >> 4)) * 512 + ((((d0 & 15) >> 3) << 5) + kap) * 8 + (d0 & 7)) =
+                to_h4(v0, v1, v2, v3);
           } else {
-            _Float16* dst = static_cast<_Float16*>(p.out2) + (((size_t)s * 4 + hd) * 64 + d0) * NP + tn;
-            dst[0] = (_Float16)v0; dst[NP] = (_Float16)v1; dst[2 * (size_t)NP] = (_Float16)v2; dst[3 * (size_t)NP] = (_Float16)v3;
+            // V: A-fragment order of the PV MFMA: [tile][kk = key/16][mt = d/32][lane = hh*32 + d%32][e],
+            // key%16 = r -> hh = (r%8)/4, e = r%4 + 4*(r/8)   (the key permutation of the swapped QK^T C-layout)
+            const int kk = kap >> 4, r = kap & 15;
+            const int hh2 = (r & 7) >> 2, ee = (r & 3) + ((r >> 3) << 2);
+            _Float16* dst = static_cast<_Float16*>(p.out2) + ((tile * 2 + kk) * 2 + (d0 >> 5)) * 512 + ((hh2 << 5) + (d0 & 31)) * 8 + ee;
+            dst[0] = (_Float16)v0; dst[8] = (_Float16)v1; dst[16] = (_Float16)v2; dst[24] = (_Float16)v3;
           }
         }
     }
@@ -135,19 +143,22 @@ hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope
                            _Float16* q, _Float16* k, _Float16* vt, hipStream_t s) {
   IgemmArgs a = token_args(w, x, 256, nullptr, 0, d);
   a.out0 = q; a.out1 = k; a.out2 = vt; a.aux = rope; a.flags = rope_segs | (t_seg << 4);
-  return launch_igemm<1, 256, 128, 8, EpiHeads>(a, w.cout_pad, s);
+  return launch_igemm<1, 256, 128, 4, EpiHeads>(a, w.cout_pad, s);
 }
 hipError_t lg_linear_f16(const ConvW& w, const _Float16* in0, int cs0, const _Float16* in1, int cs1, LgDims d,
                          _Float16* out, int ostride, hipStream_t s) {
   IgemmArgs a = token_args(w, in0, cs0, in1, cs1, d);
   a.out0 = out; a.ostride = ostride;
-  if (w.cin == 256) return launch_igemm<1, 256, 128, 8, EpiF16<false, false>>(a, w.cout_pad, s);
-  return launch_igemm<1, 512, 128, 8, EpiF16<false, false>>(a, w.cout_pad, s);
+  if (w.cin == 256) {
+    if (w.ct == 64) return launch_igemm<1, 256, 64, 4, EpiF16<false, false>>(a, w.cout_pad, s);
+    return launch_igemm<1, 256, 128, 4, EpiF16<false, false>>(a, w.cout_pad, s);
+  }
+  return launch_igemm<1, 512, 128, 4, EpiF16<false, false>>(a, w.cout_pad, s);
 }
 hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d, _Float16* x, hipStream_t s) {
   IgemmArgs a = token_args(w, in, cs, nullptr, 0, d);
   a.out0 = x; a.ostride = 256;
-  return launch_igemm<1, 512, 128, 8, EpiResid>(a, w.cout_pad, s);
+  return launch_igemm<1, 512, 64, 4, EpiResid>(a, w.cout_pad, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -163,30 +174,51 @@ hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d,
 __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                       const _Float16* __restrict__ vt, const int* __restrict__ lens,
                                                       int NP, int cross, _Float16* __restrict__ ctx) {
+  // One workgroup = 32 queries of one (sequence, head); its 4 waves split the KEYS (tile kt -> wave kt & 3,
+  // flash-decoding style) and merge their (m, l, O) partials through LDS.  4x shorter dependent chains and
+  // 4x more resident waves than one-wave-per-32-queries: the kernel is latency-bound, not MFMA-bound, at N<=1024.
+  __shared__ float s_part[4][34][64];  // [wave][32 O regs + m + l][lane]
   const int s = blockIdx.z, h = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * 32;
   const int sk = cross ? (s ^ 1) : s;
   const int nq = lens[s], nk = lens[sk];
-  if (q0 >= nq) return;
-  const _Float16* Q = q + ((size_t)(s * 4 + h) * NP) * 64;
-  const _Float16* K = k + ((size_t)(sk * 4 + h) * NP) * 64;
-  const _Float16* VT = vt + ((size_t)(sk * 4 + h) * 64) * NP;
+  if (q0 >= nq) return;  // uniform for the whole workgroup
+  // Q/K/V are stored in MFMA-fragment order per 32-token tile (EpiHeads): every operand load below is one
+  // fully coalesced 1-KiB wave load (16 B per lane, lane-linear).
+  const int nt32 = NP >> 5;
+  const _Float16* Q = q + ((size_t)(s * 4 + h) * nt32) * 2048;
+  const _Float16* K = k + ((size_t)(sk * 4 + h) * nt32) * 2048;
+  const _Float16* VT = vt + ((size_t)(sk * 4 + h) * nt32) * 2048;
   h8_t qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const h8_t*>(Q + (size_t)(q0 + j) * 64 + ks * 16 + hh * 8);
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)blockIdx.x * 4 + ks) * 512 + lane * 8);
   float m = -INFINITY, l = 0.f;
   f16x_t o[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-  for (int k0 = 0; k0 < nk; k0 += 32) {
+  const int ntiles = (nk + 31) >> 5;
+  h8_t kf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)min(wave, nt32 - 1) * 4 + ks) * 512 + lane * 8);
+  for (int kt = wave; kt < ntiles; kt += 4) {
+    const int k0 = kt * 32;
+    // V^T fragments of this tile and K fragments of the wave's next tile: issued before the MFMAs that hide them
+    h8_t vf[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)kt * 2 + kk) * 2 + mt) * 512 + lane * 8);
     f16x_t st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const h8_t a = *reinterpret_cast<const h8_t*>(K + (size_t)(k0 + j) * 64 + ks * 16 + hh * 8);
-      st = mfma32(a, qf[ks], st);
+    for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
+    if (kt + 4 < ntiles) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)(kt + 4) * 4 + ks) * 512 + lane * 8);
     }
     float tmax = -INFINITY;
 #pragma unroll
@@ -213,63 +245,201 @@ __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict
       for (int e = 0; e < 8; ++e) pb[e] = (_Float16)p[8 * kk + e];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const _Float16* vp = VT + (size_t)(mt * 32 + j) * NP + k0 + 16 * kk + 4 * hh;
-        const h4_t lo = *reinterpret_cast<const h4_t*>(vp);
-        const h4_t hi = *reinterpret_cast<const h4_t*>(vp + 8);
-        h8_t a;
-        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-        o[mt] = mfma32(a, pb, o[mt]);
+        o[mt] = mfma32(vf[kk][mt], pb, o[mt]);
       }
     }
   }
-  const float lt = l + __shfl_xor(l, 32, 64);
+  l += __shfl_xor(l, 32, 64);
+  // ---- merge the 4 key-partials ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s_part[wave][r][lane] = o[0][r]; s_part[wave][16 + r][lane] = o[1][r]; }
+  s_part[wave][32][lane] = m;
+  s_part[wave][33][lane] = l;
+  __syncthreads();
+  float mw[4], mt_all = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { mw[w] = s_part[w][32][lane]; mt_all = fmaxf(mt_all, mw[w]); }
+  float sc[4], lt = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    sc[w] = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - mt_all);
+    lt += s_part[w][33][lane] * sc[w];
+  }
   const float inv = lt > 0.f ? 1.0f / lt : 0.f;
   _Float16* orow = ctx + ((size_t)s * NP + q0 + j) * 256 + h * 64;
+  // wave w finalises combined registers R = 8w .. 8w+7 (R = mt*16 + r): two groups of 4 consecutive channels
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int gq = 0; gq < 2; ++gq) {
+    const int R0 = wave * 8 + gq * 4;
+    float v[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d = mt * 32 + hh * 4 + g * 8;
-      *reinterpret_cast<h4_t*>(orow + d) =
-          to_h4(o[mt][4 * g + 0] * inv, o[mt][4 * g + 1] * inv, o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv);
+    for (int e = 0; e < 4; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc += s_part[w][R0 + e][lane] * sc[w];
+      v[e] = acc * inv;
     }
+    const int mt = R0 >> 4, r = R0 & 15;
+    const int d = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    *reinterpret_cast<h4_t*>(orow + d) = to_h4(v[0], v[1], v[2], v[3]);
+  }
 }
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                          _Float16* ctx, hipStream_t s) {
-  hipLaunchKernelGGL(k_lg_attention, dim3(d.NP / 128, 4, d.S), dim3(256), 0, s, q, k, vt, lens, d.NP, cross ? 1 : 0,
+  hipLaunchKernelGGL(k_lg_attention, dim3(d.NP / 32, 4, d.S), dim3(256), 0, s, q, k, vt, lens, d.NP, cross ? 1 : 0,
                      ctx);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// LayerNorm(512, affine, eps 1e-5) + exact (erf) GELU, in place, one wave per token (8 values per lane).
+// Fused FFN block: x += ffn.3( GELU( LayerNorm( ffn.0( cat[x, ctx] ) ) ) ), one launch per block.
+//   * out_proj / to_out is folded into ffn.0 on the host:  W' = [W0a | W0b Wo],  b' = b0 + W0b bo
+//     (cat[x, Wo ctx + bo] W0^T  ==  cat[x, ctx] W'^T + b'), so the attention output feeds the FFN directly.
+//   * a workgroup (8 waves) owns 64 tokens; cat[x, ctx] (64 x 512 fp16) is staged once in LDS and is the MFMA
+//     B operand of ffn.0; wave w owns output rows [64w, 64w+64) and streams its packed A fragments straight
+//     from L2 (no sharing between waves -> no point in staging weights through LDS);
+//   * LayerNorm statistics: lane-local over the accumulators, lane^32 exchange, then across the 8 waves via LDS
+//     (two rounds: mean, then centred variance); exact-erf GELU on the accumulators;
+//   * the activated hidden tile overwrites the LDS input tile and is the B operand of ffn.3 (wave w owns 32 output
+//     rows); the residual add reads x from global in fp32 and writes it back in place.
+// Removes per block: 2 kernel launches and the [T,512] hidden round trip (write + read + write + read).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lg_ln_gelu(_Float16* __restrict__ h, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, int tokens) {
-  const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (token >= tokens) return;
-  h8_t* p = reinterpret_cast<h8_t*>(h + (size_t)token * 512 + lane * 8);
-  const h8_t v = *p;
-  float f[8];
-  float sum = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { f[e] = (float)v[e]; sum += f[e]; }
-  const float mean = wave_sum(sum) * (1.0f / 512.0f);
-  float sq = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { f[e] -= mean; sq += f[e] * f[e]; }
-  const float rstd = rsqrtf(wave_sum(sq) * (1.0f / 512.0f) + 1e-5f);
-  h8_t o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float y = f[e] * rstd * gamma[lane * 8 + e] + beta[lane * 8 + e];
-    o[e] = (_Float16)(0.5f * y * (1.0f + erff(y * 0.70710678118654752f)));
+constexpr int kFfnTok = 64, kFfnLd = 520;
+__global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
+                                                const float* __restrict__ b0, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, const _Float16* __restrict__ w3p,
+                                                const float* __restrict__ b3, _Float16* __restrict__ x) {
+  __shared__ __attribute__((aligned(16))) _Float16 s_x[kFfnTok * kFfnLd];
+  __shared__ float s_red[8][kFfnTok];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const size_t t0 = (size_t)blockIdx.x * kFfnTok;
+  for (int u = tid; u < kFfnTok * 64; u += 512) {
+    const int tok = u >> 6, part = u & 63;
+    const _Float16* src = part < 32 ? x + (t0 + tok) * 256 + part * 8 : ctx + (t0 + tok) * 256 + (part - 32) * 8;
+    *reinterpret_cast<uint4*>(s_x + tok * kFfnLd + part * 8) = *reinterpret_cast<const uint4*>(src);
   }
-  *p = o;
+  __syncthreads();
+  // ---- ffn.0 : rows [64 wave, +64) x 64 tokens, K = 512 ----
+  f16x_t acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  {
+    const _Float16* wp = w0p + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
+#pragma unroll 8
+    for (int ks = 0; ks < 32; ++ks) {
+      const h8_t a0 = *reinterpret_cast<const h8_t*>(wp + (ks * 2 + 0) * 512);
+      const h8_t a1 = *reinterpret_cast<const h8_t*>(wp + (ks * 2 + 1) * 512);
+      const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
+      const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
+      acc[0][0] = mfma32(a0, bf0, acc[0][0]);
+      acc[0][1] = mfma32(a0, bf1, acc[0][1]);
+      acc[1][0] = mfma32(a1, bf0, acc[1][0]);
+      acc[1][1] = mfma32(a1, bf1, acc[1][1]);
+    }
+  }
+  // ---- bias, LayerNorm(512) over the row dimension (spread over regs, lane^32 and the 8 waves), GELU ----
+  float sum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *reinterpret_cast<const float4*>(b0 + wave * 64 + m * 32 + hh * 4 + g * 8);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        acc[m][n][4 * g + 0] += bv.x; acc[m][n][4 * g + 1] += bv.y; acc[m][n][4 * g + 2] += bv.z; acc[m][n][4 * g + 3] += bv.w;
+        sum[n] += (acc[m][n][4 * g + 0] + acc[m][n][4 * g + 1]) + (acc[m][n][4 * g + 2] + acc[m][n][4 * g + 3]);
+      }
+    }
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    sum[n] += __shfl_xor(sum[n], 32, 64);
+    if (hh == 0) s_red[wave][n * 32 + j] = sum[n];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
+    mean[n] = t * (1.0f / 512.0f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    float sq = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float dlt = acc[m][n][r] - mean[n]; sq += dlt * dlt; }
+    sq += __shfl_xor(sq, 32, 64);
+    if (hh == 0) s_red[wave][n * 32 + j] = sq;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
+    rstd[n] = rsqrtf(t * (1.0f / 512.0f) + 1e-5f);
+  }
+  // every wave has passed two barriers since its last read of s_x: the tile can be overwritten with the hidden tile
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = wave * 64 + m * 32 + hh * 4 + g * 8;
+      const float4 gv = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 be = *reinterpret_cast<const float4*>(beta + c);
+      const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = (acc[m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
+          o[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));
+        }
+        *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  __syncthreads();
+  // ---- ffn.3 : rows [32 wave, +32) x 64 tokens, K = 512, + residual ----
+  f16x_t ac2[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ac2[n][r] = 0.f;
+  {
+    const _Float16* wp = w3p + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
+#pragma unroll 8
+    for (int ks = 0; ks < 32; ++ks) {
+      const h8_t a0 = *reinterpret_cast<const h8_t*>(wp + ks * 512);
+      const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
+      const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
+      ac2[0] = mfma32(a0, bf0, ac2[0]);
+      ac2[1] = mfma32(a0, bf1, ac2[1]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = wave * 32 + hh * 4 + g * 8;
+    const float4 bv = *reinterpret_cast<const float4*>(b3 + c);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
+      const h4_t o = *px;
+      *px = to_h4((float)o[0] + (ac2[n][4 * g + 0] + bv.x), (float)o[1] + (ac2[n][4 * g + 1] + bv.y),
+                  (float)o[2] + (ac2[n][4 * g + 2] + bv.z), (float)o[3] + (ac2[n][4 * g + 3] + bv.w));
+    }
+  }
 }
-void launch_lg_ln_gelu(_Float16* h, const float* gamma, const float* beta, int tokens, hipStream_t s) {
-  hipLaunchKernelGGL(k_lg_ln_gelu, dim3((tokens + 3) / 4), dim3(256), 0, s, h, gamma, beta, tokens);
+void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
+                   _Float16* x, int tokens, hipStream_t s) {
+  hipLaunchKernelGGL(k_lg_ffn, dim3(tokens / kFfnTok), dim3(512), 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x);
 }
 
 // logsigmoid(matchability(x)) per token.

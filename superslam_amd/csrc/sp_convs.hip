@@ -35,7 +35,7 @@ hipError_t sp_conv1x1_f16(const ConvW& w, const _Float16* in, _Float16* out, int
   IgemmArgs a = conv_args(w, in, B, H, W);
   a.out0 = out;
   if (w.cin != 256) return hipErrorInvalidValue;
-  return launch_igemm<1, 256, 128, 8, EpiF16<false, false>>(a, w.cout_pad, s);
+  return launch_igemm<1, 256, 128, 4, EpiF16<false, false>>(a, w.cout_pad, s);
 }
 
 hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int ostride, int B, int H, int W,
@@ -43,7 +43,7 @@ hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int os
   IgemmArgs a = conv_args(w, in, B, H, W);
   a.out0 = out; a.ostride = ostride;
   if (w.cin != 256) return hipErrorInvalidValue;
-  return launch_igemm<1, 256, 128, 8, EpiF32>(a, w.cout_pad, s);
+  return launch_igemm<1, 256, 128, 4, EpiF32>(a, w.cout_pad, s);
 }
 
 }  // namespace sship

@@ -86,6 +86,8 @@ template <int LOADER>
 __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
   __shared__ float s_s[NLH * NLS];
   __shared__ float s_r[NLH * NT_W];
+  __shared__ unsigned long long s_c[NT_H * NT_W];
+  __shared__ int s_cnt, s_base;
   const int tiles_x = (a.W + NT_W - 1) / NT_W, tiles_y = (a.H + NT_H - 1) / NT_H;
   int t = blockIdx.x;
   const int tx = t % tiles_x; t /= tiles_x;
@@ -96,20 +98,44 @@ __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
   if constexpr (LOADER == 0) {
     const int Hc = a.H >> 3, Wc = a.W >> 3;
     const int cy0 = y0 >> 3, cx0 = x0 >> 3;  // may be -1
-    for (int cell = wave; cell < (NLH / 8) * (NLW / 8); cell += 4) {
+    // 60 cells (6 x 10 incl. the halo ring) x 4 lanes: each lane owns 16 of the 64 position channels, the group
+    // of 4 shares max / sum through two DPP exchanges - one parallel pass, no per-cell serial loop.
+    constexpr int NCELL = (NLH / 8) * (NLW / 8);
+    if (tid < NCELL * 4) {
+      const int cell = tid >> 2, qd = tid & 3;
       const int cyl = cell / (NLW / 8), cxl = cell % (NLW / 8);
       const int cy = cy0 + cyl, cx = cx0 + cxl;
-      float sc = -INFINITY;
-      if (cy >= 0 && cy < Hc && cx >= 0 && cx < Wc) {
+      float v[16];
+      float d = 0.f;
+      const bool in = cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+      if (in) {
         const float* lp = a.logits + ((size_t)(b * Hc + cy) * Wc + cx) * a.ls;
-        const float v = lp[lane];
-        const float d = lp[64];
-        const float m = fmaxf(wave_max(v), d);
-        const float e = expf(v - m);
-        const float sum = wave_sum(e) + expf(d - m);
-        sc = e / sum;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 t4 = *reinterpret_cast<const float4*>(lp + qd * 16 + i * 4);
+          v[4 * i] = t4.x; v[4 * i + 1] = t4.y; v[4 * i + 2] = t4.z; v[4 * i + 3] = t4.w;
+        }
+        d = lp[64];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
       }
-      s_s[(cyl * 8 + (lane >> 3)) * NLS + cxl * 8 + (lane & 7)] = sc;
+      float m = d;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m = fmaxf(m, v[i]);
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - m); sum += v[i]; }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += expf(d - m);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = qd * 16 + i;
+        s_s[(cyl * 8 + (c >> 3)) * NLS + cxl * 8 + (c & 7)] = in ? v[i] / sum : -INFINITY;
+      }
     }
   } else {
     for (int i = tid; i < NLH * NLW; i += 256) {
@@ -129,6 +155,7 @@ __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
     for (int d = -R; d <= R; ++d) m = fmaxf(m, s_s[ly * NLS + lx + d]);
     s_r[ly * NT_W + (lx - NHALO)] = m;
   }
+  if (tid == 0) s_cnt = 0;
   __syncthreads();
   for (int i = tid; i < NT_H * NT_W; i += 256) {
     const int iy = i / NT_W, ix = i % NT_W;
@@ -144,11 +171,20 @@ __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
     if (a.scores_out) a.scores_out[o] = is_max ? s : 0.0f;
     if (a.cand && is_max && s >= a.thr_f && gy >= a.border && gy < a.H - a.border && gx >= a.border &&
         gx < a.W - a.border) {
-      const int idx = atomicAdd(&a.cand_count[b], 1);
-      if (idx < a.cap)
-        a.cand[(size_t)b * a.cap + idx] =
-            ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(gy * a.W + gx);
+      // workgroup-local compaction first: ONE global atomic per tile instead of one per candidate (the 16 per-image
+      // counters were the bottleneck: ~7k same-address L2 atomics per image serialise)
+      const int li = atomicAdd(&s_cnt, 1);
+      s_c[li] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(gy * a.W + gx);
     }
+  }
+  if (a.cand) {
+    __syncthreads();
+    const int n = s_cnt;
+    if (tid == 0) s_base = n ? atomicAdd(&a.cand_count[b], n) : 0;
+    __syncthreads();
+    const int base = s_base;
+    for (int i = tid; i < n; i += 256)
+      if (base + i < a.cap) a.cand[(size_t)b * a.cap + base + i] = s_c[i];
   }
 }
 
