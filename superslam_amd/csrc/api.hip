@@ -446,8 +446,9 @@ extern "C" int sship_select_topk(const float* scores, int score_h, int score_w, 
 struct sship_sp {
   sship_sp_config cfg{};
   hipStream_t stream = nullptr;
-  float* w1a = nullptr;  // [9][64] tap-major fp32 (fp16-rounded values)
+  float* w1a = nullptr;  // [9][64] tap-major fp32 (fp16-rounded values)  (stand-alone conv1a kernel)
   float* b1a = nullptr;
+  _Float16* w1a_frag = nullptr;  // conv1a as MFMA A fragments [2][64][8] (K = 9 taps zero-padded to 16)
   ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, cPa, cPb, cDa, cDb;
   sship_pool* pool = nullptr;
   // activations (channels-last fp16), sized for (B, H, W)
@@ -502,18 +503,19 @@ static int sp_ensure(sship_sp* sp, int B, int H, int W) {
 static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hipStream_t s) {
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
-  launch_conv1a(imgs, sp->w1a, sp->b1a, sp->a1a.as<_Float16>(), B, H, W, s);
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->c1b, sp->a1a.as<_Float16>(), sp->a1b.as<_Float16>(), B, H, W, true, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->c4a, sp->a3b.as<_Float16>(), sp->a4a.as<_Float16>(), B, Hc, Wc, false, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->c4b, sp->a4a.as<_Float16>(), sp->a4b.as<_Float16>(), B, Hc, Wc, false, true, s));
+  // conv1a is evaluated inside conv1b's tile staging (conv_strip.hip): the 64-channel full-resolution activation
+  // never exists in HBM.
+  SSHIP_HIP_CHECK(sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c4a, sp->a3b.as<_Float16>(), sp->a4a.as<_Float16>(), B, Hc, Wc, false, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c4b, sp->a4a.as<_Float16>(), sp->a4b.as<_Float16>(), B, Hc, Wc, false, s));
   g_timer.mark("sp_encoder", s);
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, s));
   SSHIP_HIP_CHECK(sp_conv1x1_f32(sp->cPb, sp->aPa.as<_Float16>(), sp->logits.as<float>(), kLogitStride, B, Hc, Wc, s));
-  SSHIP_HIP_CHECK(sp_conv3x3(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, true, s));
+  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
   SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
   g_timer.mark("sp_heads", s);
   return SSHIP_OK;
@@ -559,9 +561,9 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
   struct L { const char* name; int cout, cin, ks, ct; ConvW* dst; };
   const L layers[] = {{"conv1b", 64, 64, 3, 64, &sp->c1b}, {"conv2a", 64, 64, 3, 64, &sp->c2a},
                       {"conv2b", 64, 64, 3, 64, &sp->c2b}, {"conv3a", 128, 64, 3, 64, &sp->c3a},
-                      {"conv3b", 128, 128, 3, 64, &sp->c3b}, {"conv4a", 128, 128, 3, 64, &sp->c4a},
-                      {"conv4b", 128, 128, 3, 64, &sp->c4b}, {"convPa", 256, 128, 3, 64, &sp->cPa},
-                      {"convPb", 65, 256, 1, 128, &sp->cPb}, {"convDa", 256, 128, 3, 64, &sp->cDa},
+                      {"conv3b", 128, 128, 3, 32, &sp->c3b}, {"conv4a", 128, 128, 3, 32, &sp->c4a},
+                      {"conv4b", 128, 128, 3, 32, &sp->c4b}, {"convPa", 256, 128, 3, 32, &sp->cPa},
+                      {"convPb", 65, 256, 1, 128, &sp->cPb}, {"convDa", 256, 128, 3, 32, &sp->cDa},
                       {"convDb", 256, 256, 1, 128, &sp->cDb}};
   for (const L& l : layers) {
     const Tensor* w = find_tensor(sd, std::string(l.name) + ".weight", {l.cout, l.cin, l.ks, l.ks}, err);
@@ -578,6 +580,15 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
       for (int t = 0; t < 9; ++t) wt[t * 64 + co] = (float)(_Float16)w->data[co * 9 + t];  // fp16 engine weights
     if (int rc = upload_floats(wt.data(), 576, &sp->w1a)) return rc;
     if (int rc = upload_floats(b->data.data(), 64, &sp->b1a)) return rc;
+    std::vector<_Float16> fr(2 * 64 * 8);
+    for (int mt = 0; mt < 2; ++mt)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int co = mt * 32 + (lane & 31), k = (lane >> 5) * 8 + e;
+          fr[(mt * 64 + lane) * 8 + e] = (_Float16)(k < 9 ? w->data[co * 9 + k] : 0.f);
+        }
+    SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp->w1a_frag), fr.size() * sizeof(_Float16)));
+    SSHIP_HIP_CHECK(hipMemcpy(sp->w1a_frag, fr.data(), fr.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   }
   SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
   if (int rc = sship_pool_create(sp->cfg.pool_slots, sp->cfg.max_keypoints, SSHIP_DESC_DIM, &sp->pool)) return rc;
@@ -591,6 +602,7 @@ extern "C" void sship_sp_destroy(sship_sp* sp) {
     free_conv(*c);
   if (sp->w1a) (void)hipFree(sp->w1a);
   if (sp->b1a) (void)hipFree(sp->b1a);
+  if (sp->w1a_frag) (void)hipFree(sp->w1a_frag);
   if (sp->pool) sship_pool_destroy(sp->pool);
   if (sp->stream) (void)hipStreamDestroy(sp->stream);
   delete sp;
@@ -648,23 +660,23 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
            *aDa = sp->aDa.as<_Float16>();
   auto run = [&]() -> hipError_t {
     switch (layer) {
-      case 0: launch_conv1a(sp->img.as<uint8_t>(), sp->w1a, sp->b1a, a1a, batch, h, w, s); return hipGetLastError();
-      case 1: return sp_conv3x3(sp->c1b, a1a, a1b, batch, h, w, true, true, s);
-      case 2: return sp_conv3x3(sp->c2a, a1b, a2a, batch, H2, W2, false, true, s);
-      case 3: return sp_conv3x3(sp->c2b, a2a, a2b, batch, H2, W2, true, true, s);
-      case 4: return sp_conv3x3(sp->c3a, a2b, a3a, batch, H4, W4, false, true, s);
-      case 5: return sp_conv3x3(sp->c3b, a3a, a3b, batch, H4, W4, true, true, s);
-      case 6: return sp_conv3x3(sp->c4a, a3b, a4a, batch, Hc, Wc, false, true, s);
-      case 7: return sp_conv3x3(sp->c4b, a4a, a4b, batch, Hc, Wc, false, true, s);
-      case 8: return sp_conv3x3(sp->cPa, a4b, aPa, batch, Hc, Wc, false, true, s);
+      case 0: launch_conv1a(sp->img.as<uint8_t>(), sp->w1a, sp->b1a, a1a, batch, h, w, s); return hipGetLastError();  // stand-alone (not on the path)
+      case 1: return sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, sp->img.as<uint8_t>(), a1b, batch, h, w, s);
+      case 2: return sp_conv3x3_strip(sp->c2a, a1b, a2a, batch, H2, W2, false, s);
+      case 3: return sp_conv3x3_strip(sp->c2b, a2a, a2b, batch, H2, W2, true, s);
+      case 4: return sp_conv3x3_strip(sp->c3a, a2b, a3a, batch, H4, W4, false, s);
+      case 5: return sp_conv3x3_strip(sp->c3b, a3a, a3b, batch, H4, W4, true, s);
+      case 6: return sp_conv3x3_strip(sp->c4a, a3b, a4a, batch, Hc, Wc, false, s);
+      case 7: return sp_conv3x3_strip(sp->c4b, a4a, a4b, batch, Hc, Wc, false, s);
+      case 8: return sp_conv3x3_strip(sp->cPa, a4b, aPa, batch, Hc, Wc, false, s);
       case 9: return sp_conv1x1_f32(sp->cPb, aPa, sp->logits.as<float>(), kLogitStride, batch, Hc, Wc, s);
-      case 10: return sp_conv3x3(sp->cDa, a4b, aDa, batch, Hc, Wc, false, true, s);
+      case 10: return sp_conv3x3_strip(sp->cDa, a4b, aDa, batch, Hc, Wc, false, s);
       default: return sp_conv1x1_f16(sp->cDb, aDa, sp->draw.as<_Float16>(), batch, Hc, Wc, s);
     }
   };
   const double px[12] = {(double)h * w, (double)h * w, (double)H2 * W2, (double)H2 * W2, (double)H4 * W4, (double)H4 * W4,
                          (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc};
-  const double mpp[12] = {9.0 * 64, 576.0 * 64, 576.0 * 64, 576.0 * 64, 576.0 * 128, 1152.0 * 128, 1152.0 * 128,
+  const double mpp[12] = {9.0 * 64, 576.0 * 64 + 9.0 * 64 /* conv1a fused */, 576.0 * 64, 576.0 * 64, 576.0 * 128, 1152.0 * 128, 1152.0 * 128,
                           1152.0 * 128, 1152.0 * 256, 256.0 * 65, 1152.0 * 256, 256.0 * 256};
   if (macs) *macs = px[layer] * mpp[layer] * batch;
   SSHIP_HIP_CHECK(run());  // warm

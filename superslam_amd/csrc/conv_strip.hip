@@ -1,0 +1,309 @@
+// Persistent-strip 3x3 convolution for SuperPoint's encoder / head convs (utils/convert_superpoint_to_onnx.py:38-49).
+//
+// Why a second conv kernel: the generic igemm kernel spends ~7.5 VALU instructions per MFMA on per-tile prologue /
+// epilogue work (rocprofv3 PMC, profiles/r01_v2_pmc_conv1b.txt: MFMA busy 24 %, no LDS conflicts, 46 % of wave
+// cycles waiting at barriers/waitcnt).  Here a workgroup is persistent over a strip of tiles and everything that
+// does not depend on the tile is hoisted out of the tile loop:
+//   * the layer's weights for the workgroup's output-channel block (all 9 taps, 72 KiB) are staged into LDS ONCE;
+//   * 8 waves share a 16 x 32 pixel tile (wave w: rows 2w, 2w+1 -> 2 N-tiles), 144 MFMAs per wave per tile with NO
+//     barrier inside the 36-k-step loop;
+//   * the next tile's input (64 channels, 18 x 34 halo tile) is prefetched into registers while the MFMAs of the
+//     current tile run, and written to the single LDS tile buffer between two barriers;
+//   * per-thread staging offsets are computed once per launch; interior tiles take a branch-free load path;
+//   * FUSE1A (conv1b): the input tile is not read from HBM at all - conv1a (1 -> 64 channels, K = 9 padded to 16)
+//     is evaluated with MFMAs from a 20 x 36 u8 image patch straight into the LDS tile (u8 -> x 1/255 -> fp16,
+//     bias, ReLU, zero outside the image).  Removes the 128 B/pixel conv1a activation round trip (2 x 66 MB per
+//     image) and the separate conv1a launch.
+// LDS: 18*34*144 B input tile + 72 KiB weights (+ 1.6 KiB patch) = 161.9 KiB of the CU's 160 KiB... i.e. 163,840 B.
+//   CIN = 64 : CT = 64 output channels per workgroup (MT = 2)
+//   CIN = 128: CT = 32 (MT = 1), two 64-channel chunks per tile through the same tile buffer (2 more barriers)
+#include "igemm.h"
+#include "kernels.h"
+
+namespace sship {
+
+struct StripArgs {
+  const _Float16* in;    // channels-last fp16 [B,H,W,CIN]   (unused when FUSE1A)
+  const uint8_t* img;    // u8 [B,H,W]                        (FUSE1A)
+  const _Float16* w1a;   // conv1a A fragments [2][64][8] fp16 (FUSE1A)
+  const float* b1a;      // conv1a bias [64]                  (FUSE1A)
+  const _Float16* wpack; // packed weights [cb][chunk][tap][kstep][mt][lane][8]
+  const float* bias;
+  _Float16* out;
+  int B, H, W, cout;
+};
+
+constexpr int S_TH = 16, S_TW = 32, S_THH = 18, S_TWH = 34;
+constexpr int S_IN_HALFS = S_THH * S_TWH * kCP;        // 44,064 halfs = 88,128 B
+constexpr int S_W_HALFS = 36864;                       // 72 KiB
+constexpr int S_IN_UNITS = S_THH * S_TWH * 8;          // 4896 sixteen-byte units
+constexpr int S_IN_IT = (S_IN_UNITS + 511) / 512;      // 10
+constexpr int S_PATCH_W = 36, S_PATCH_H = 20;
+
+template <int CIN, int CT, bool POOL, bool FUSE1A>
+__global__ __launch_bounds__(512) void conv3x3_strip(StripArgs p) {
+  constexpr int MT = CT / 32, NCHUNK = CIN / 64;
+  static_assert(NCHUNK * 9 * 4 * MT * 512 == S_W_HALFS, "weights must fill exactly 72 KiB");
+  static_assert(!FUSE1A || CIN == 64, "conv1a fusion feeds a 64-channel layer");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  _Float16* s_in = reinterpret_cast<_Float16*>(smem);
+  _Float16* s_w = s_in + S_IN_HALFS;
+  _Float16* s_patch = s_w + S_W_HALFS;  // FUSE1A: 20 x 36 fp16 image patch
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int tiles_x = (p.W + S_TW - 1) / S_TW, tiles_y = (p.H + S_TH - 1) / S_TH;
+  const int ntiles = p.B * tiles_x * tiles_y;
+  const int cb = blockIdx.y;
+  const int t_begin = (int)((long long)blockIdx.x * ntiles / gridDim.x);
+  const int t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  if (t_begin >= t_end) return;
+
+  // ---- weights: once per workgroup ----
+  {
+    const _Float16* wsrc = p.wpack + (size_t)cb * S_W_HALFS;
+    for (int u = tid; u < S_W_HALFS / 8; u += 512)
+      *reinterpret_cast<uint4*>(s_w + u * 8) = *reinterpret_cast<const uint4*>(wsrc + u * 8);
+  }
+  // ---- per-thread staging geometry (tile independent) ----
+  int g_off[S_IN_IT];   // element offset relative to the halo-tile origin pixel, channel chunk 0
+  int l_off[S_IN_IT];   // LDS half offset
+  short py_[S_IN_IT], px_[S_IN_IT];
+#pragma unroll
+  for (int i = 0; i < S_IN_IT; ++i) {
+    const int u = tid + i * 512;
+    const int pix = u >> 3, part = u & 7;
+    const int py = pix / S_TWH, px = pix - py * S_TWH;
+    py_[i] = (short)py; px_[i] = (short)px;
+    g_off[i] = (py * p.W + px) * CIN + part * 8;
+    l_off[i] = pix * kCP + part * 8;
+  }
+  const bool last_it_valid = (tid + (S_IN_IT - 1) * 512) < S_IN_UNITS;
+
+  uint4 rin[S_IN_IT];
+  unsigned rpatch = 0;  // FUSE1A: 4 u8 of the next tile's patch per thread (threads 0..179)
+
+  auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % tiles_x;
+    const int r = t / tiles_x;
+    x0 = tx * S_TW; y0 = (r % tiles_y) * S_TH; b = r / tiles_y;
+  };
+  auto load_in = [&](int t, int chunk) {
+    int b, y0, x0;
+    tile_coords(t, b, y0, x0);
+    const _Float16* base = p.in + ((size_t)(b * p.H + (y0 - 1)) * p.W + (x0 - 1)) * CIN + chunk * 64;
+    const bool interior = y0 >= 1 && y0 + S_TH + 1 <= p.H && x0 >= 1 && x0 + S_TW + 1 <= p.W;
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < S_IN_IT; ++i)
+        if (i < S_IN_IT - 1 || last_it_valid) rin[i] = *reinterpret_cast<const uint4*>(base + g_off[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < S_IN_IT; ++i) {
+        const int gy = y0 - 1 + py_[i], gx = x0 - 1 + px_[i];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((i < S_IN_IT - 1 || last_it_valid) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+          v = *reinterpret_cast<const uint4*>(base + g_off[i]);
+        rin[i] = v;
+      }
+    }
+  };
+  auto store_in = [&]() {
+#pragma unroll
+    for (int i = 0; i < S_IN_IT; ++i)
+      if (i < S_IN_IT - 1 || last_it_valid) *reinterpret_cast<uint4*>(s_in + l_off[i]) = rin[i];
+  };
+  // FUSE1A: thread (r = tid / 9, c4 = tid % 9) holds patch row r, columns 4*c4 .. 4*c4+3
+  auto load_patch = [&](int t) {
+    if (tid < S_PATCH_H * 9) {
+      int b, y0, x0;
+      tile_coords(t, b, y0, x0);
+      const int r = tid / 9, c4 = tid - r * 9;
+      const int gy = y0 - 2 + r, gx = x0 - 2 + c4 * 4;
+      unsigned v = 0;
+      if (gy >= 0 && gy < p.H) {
+        const uint8_t* row = p.img + ((size_t)b * p.H + gy) * p.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int x = gx + k;
+          if (x >= 0 && x < p.W) v |= (unsigned)row[x] << (8 * k);
+        }
+      }
+      rpatch = v;
+    }
+  };
+  auto store_patch = [&]() {
+    if (tid < S_PATCH_H * 9) {
+      const int r = tid / 9, c4 = tid - r * 9;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        s_patch[r * S_PATCH_W + c4 * 4 + k] = (_Float16)((float)((rpatch >> (8 * k)) & 0xff) * (1.0f / 255.0f));
+    }
+  };
+  // conv1a on the matrix cores: D[cout][pixel] = W1a[cout][tap] * patch[tap][pixel], K = 9 zero-padded to 16.
+  auto conv1a_to_lds = [&](int t) {
+    int b, y0, x0;
+    tile_coords(t, b, y0, x0);
+    const h8_t a0 = *reinterpret_cast<const h8_t*>(p.w1a + lane * 8);
+    const h8_t a1 = *reinterpret_cast<const h8_t*>(p.w1a + 512 + lane * 8);
+    for (int nt = wave; nt < (S_THH * S_TWH + 31) / 32; nt += 8) {
+      const int q = nt * 32 + j;
+      const int qq = q < S_THH * S_TWH ? q : S_THH * S_TWH - 1;
+      const int py = qq / S_TWH, px = qq - py * S_TWH;
+      const _Float16* pp = s_patch + py * S_PATCH_W + px;
+      h8_t bf;
+      if (hh == 0) {
+        bf[0] = pp[0]; bf[1] = pp[1]; bf[2] = pp[2];
+        bf[3] = pp[S_PATCH_W]; bf[4] = pp[S_PATCH_W + 1]; bf[5] = pp[S_PATCH_W + 2];
+        bf[6] = pp[2 * S_PATCH_W]; bf[7] = pp[2 * S_PATCH_W + 1];
+      } else {
+        bf[0] = pp[2 * S_PATCH_W + 2];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) bf[e] = (_Float16)0.f;
+      }
+      f16x_t d0, d1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+      d0 = mfma32(a0, bf, d0);
+      d1 = mfma32(a1, bf, d1);
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool inside = q < S_THH * S_TWH && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      if (q < S_THH * S_TWH) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = hh * 4 + g * 8;
+          const float4 b0v = *reinterpret_cast<const float4*>(p.b1a + c);
+          const float4 b1v = *reinterpret_cast<const float4*>(p.b1a + 32 + c);
+          h4_t o0 = to_h4(fmaxf(d0[4 * g] + b0v.x, 0.f), fmaxf(d0[4 * g + 1] + b0v.y, 0.f), fmaxf(d0[4 * g + 2] + b0v.z, 0.f),
+                          fmaxf(d0[4 * g + 3] + b0v.w, 0.f));
+          h4_t o1 = to_h4(fmaxf(d1[4 * g] + b1v.x, 0.f), fmaxf(d1[4 * g + 1] + b1v.y, 0.f), fmaxf(d1[4 * g + 2] + b1v.z, 0.f),
+                          fmaxf(d1[4 * g + 3] + b1v.w, 0.f));
+          if (!inside) { o0 = to_h4(0.f, 0.f, 0.f, 0.f); o1 = o0; }  // conv1b's zero padding applies to conv1a's OUTPUT
+          *reinterpret_cast<h4_t*>(s_in + q * kCP + c) = o0;
+          *reinterpret_cast<h4_t*>(s_in + q * kCP + 32 + c) = o1;
+        }
+      }
+    }
+  };
+
+  if constexpr (FUSE1A) load_patch(t_begin); else load_in(t_begin, 0);
+
+  for (int t = t_begin; t < t_end; ++t) {
+    f16x_t acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+#pragma unroll
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      __syncthreads();  // all waves are done reading the tile buffer (previous tile / previous chunk)
+      if constexpr (FUSE1A) {
+        store_patch();
+        __syncthreads();
+        if (t + 1 < t_end) load_patch(t + 1);
+        conv1a_to_lds(t);
+      } else {
+        store_in();
+      }
+      __syncthreads();
+      if constexpr (!FUSE1A) {
+        if (chunk + 1 < NCHUNK) load_in(t, chunk + 1);
+        else if (t + 1 < t_end) load_in(t + 1, 0);
+      }
+      const _Float16* wc = s_w + chunk * (9 * 4 * MT * 512) + lane * 8;
+      const _Float16* ib = s_in + ((wave * 2) * S_TWH + j) * kCP + hh * 8;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          h8_t a[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const h8_t bf = *reinterpret_cast<const h8_t*>(ib + ((n + ky) * S_TWH + kx) * kCP + ks * 16);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(a[m], bf, acc[m][n]);
+          }
+        }
+      }
+    }
+    // ---- epilogue: bias + ReLU (+ 2x2 max-pool), fp16 channels-last ----
+    int b, y0, x0;
+    tile_coords(t, b, y0, x0);
+    const int yb = y0 + wave * 2, x = x0 + j;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = cb * CT + m * 32 + hh * 4 + g * 8;
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + c);
+        if constexpr (!POOL) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const int y = yb + n;
+            if (y < p.H && x < p.W)
+              *reinterpret_cast<h4_t*>(p.out + ((size_t)(b * p.H + y) * p.W + x) * p.cout + c) =
+                  to_h4(fmaxf(acc[m][n][4 * g] + bv.x, 0.f), fmaxf(acc[m][n][4 * g + 1] + bv.y, 0.f),
+                        fmaxf(acc[m][n][4 * g + 2] + bv.z, 0.f), fmaxf(acc[m][n][4 * g + 3] + bv.w, 0.f));
+          }
+        } else {
+          const int Ho = p.H >> 1, Wo = p.W >> 1;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float tt = fmaxf(acc[m][0][4 * g + e], acc[m][1][4 * g + e]);
+            v[e] = fmaxf(tt, __shfl_xor(tt, 1, 64));
+          }
+          const int yo = yb >> 1, xo = x >> 1;
+          if (!(x & 1) && yo < Ho && xo < Wo)
+            *reinterpret_cast<h4_t*>(p.out + ((size_t)(b * Ho + yo) * Wo + xo) * p.cout + c) =
+                to_h4(fmaxf(v[0] + bv.x, 0.f), fmaxf(v[1] + bv.y, 0.f), fmaxf(v[2] + bv.z, 0.f), fmaxf(v[3] + bv.w, 0.f));
+        }
+      }
+  }
+}
+
+template <int CIN, int CT, bool POOL, bool FUSE1A>
+static hipError_t launch_strip(const StripArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)(S_IN_HALFS + S_W_HALFS) * 2 + (FUSE1A ? S_PATCH_H * S_PATCH_W * 2 : 0);
+  static_assert(smem <= 163840, "LDS budget");
+  auto kern = conv3x3_strip<CIN, CT, POOL, FUSE1A>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int ncb = a.cout / CT;
+  const int ntiles = a.B * ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH);
+  int gx = 256 / ncb;  // one persistent workgroup per CU (the 160 KiB LDS footprint admits exactly one)
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kern, dim3(gx, ncb), dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t sp_conv3x3_strip(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool,
+                            hipStream_t s) {
+  StripArgs a{};
+  a.in = in; a.wpack = w.w; a.bias = w.bias; a.out = out; a.B = B; a.H = H; a.W = W; a.cout = w.cout;
+  if (w.cin == 64 && w.ct == 64) return pool ? launch_strip<64, 64, true, false>(a, s) : launch_strip<64, 64, false, false>(a, s);
+  if (w.cin == 128 && w.ct == 32) return pool ? launch_strip<128, 32, true, false>(a, s) : launch_strip<128, 32, false, false>(a, s);
+  return hipErrorInvalidValue;
+}
+
+// conv1a + conv1b + 2x2 max-pool in one launch, straight from the u8 image.
+hipError_t sp_conv1ab_fused(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img,
+                            _Float16* out, int B, int H, int W, hipStream_t s) {
+  StripArgs a{};
+  a.img = img; a.w1a = w1a_frag; a.b1a = b1a; a.wpack = w1b.w; a.bias = w1b.bias; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.cout = w1b.cout;
+  if (w1b.cin != 64 || w1b.ct != 64) return hipErrorInvalidValue;
+  return launch_strip<64, 64, true, true>(a, s);
+}
+
+}  // namespace sship

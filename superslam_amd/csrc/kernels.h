@@ -61,6 +61,10 @@ struct ConvW {          // one packed conv / linear layer on the device
 // in: channels-last fp16 [B,H,W,cin]; out: [B,Ho,Wo,cout] fp16 (pool: floor(/2)).
 hipError_t sp_conv3x3(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, bool relu,
                       hipStream_t s);
+hipError_t sp_conv3x3_strip(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool,
+                            hipStream_t s);
+hipError_t sp_conv1ab_fused(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img,
+                            _Float16* out, int B, int H, int W, hipStream_t s);
 hipError_t sp_conv1x1_f16(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s);
 hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int ostride, int B, int H, int W,
                           hipStream_t s);

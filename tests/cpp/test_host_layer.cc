@@ -75,7 +75,7 @@ static int run_gpu(const char* spw, const char* lgw) {
   LightGlue lg2(lg.shared_engine(), W, H, 300);  // second matcher on the shared weights (loop-closure thread)
   EXPECT(lg2.initialize());
   if (g_fail) return 1;
-  const auto left = make_image(H, W, 0), right = make_image(H, W, 10);  // right = left shifted by 10 px
+  const auto left = make_image(H, W, 0), right = make_image(H, W, 16);  // right = left shifted by 16 px (2 SuperPoint cells: the net is shift-equivariant only in 8-px steps)
   Image L{left.data(), H, W, 1, 0}, R{right.data(), H, W, 1, 0};
   IFeatureExtractor* ext = &sp;
   IFeatureMatcher* matcher = &lg;
@@ -85,7 +85,7 @@ static int run_gpu(const char* spw, const char* lgw) {
   EXPECT(sp.pool_in_use() == 2);
   MatchResult m = matcher->match(lr.first.keypoints, lr.first.descriptors, lr.second.keypoints, lr.second.descriptors);
   // StereoFrontEnd::process gates (src/StereoFrontEnd.cc:35-48)
-  int with_depth = 0, disparity10 = 0, ascending = 1, last = -1;
+  int with_depth = 0, disparity16 = 0, ascending = 1, last = -1;
   for (const DMatch& d : m.matches) {
     if (d.queryIdx <= last) ascending = 0;
     last = d.queryIdx;
@@ -94,13 +94,13 @@ static int run_gpu(const char* spw, const char* lgw) {
     if (a.x - b.x < 1.0f) continue;
     if (std::fabs(a.y - b.y) > 2.0f) continue;
     ++with_depth;
-    if (std::fabs((a.x - b.x) - 10.0f) < 0.5f) ++disparity10;
+    if (std::fabs((a.x - b.x) - 16.0f) < 0.5f) ++disparity16;
   }
-  std::printf("cpp: %zu/%zu keypoints, %zu matches, %d with depth, %d at disparity 10\n", lr.first.keypoints.size(),
-              lr.second.keypoints.size(), m.matches.size(), with_depth, disparity10);
+  std::printf("cpp: %zu/%zu keypoints, %zu matches, %d with depth, %d at disparity 16\n", lr.first.keypoints.size(),
+              lr.second.keypoints.size(), m.matches.size(), with_depth, disparity16);
   EXPECT(ascending);
   EXPECT(with_depth > 0);
-  EXPECT(disparity10 * 10 >= with_depth * 6);  // the synthetic pair has a constant 10 px disparity
+  EXPECT(disparity16 * 10 >= with_depth * 6);  // the synthetic pair has a constant 16 px disparity
   // zero disparity: left == right -> every gated match is rejected (MarksBelowFloorDisparityAsNoDepth)
   auto ll = ext->extract_stereo(L, L);
   MatchResult mz = matcher->match(ll.first.keypoints, ll.first.descriptors, ll.second.keypoints, ll.second.descriptors);
