@@ -789,6 +789,7 @@ struct sship_lg_weights {
   std::mutex mu;
   int refs = 1;
   ConvW qkv[kLgLayers], ffn0_s[kLgLayers], ffn3_s[kLgLayers];  // ffn0_*: out_proj / to_out folded in
+  ConvW qkv_t[kLgLayers], cqkv_t[kLgLayers], final_t;            // same projections packed per wave for the FFN tail
   ConvW cqkv[kLgLayers], ffn0_c[kLgLayers], ffn3_c[kLgLayers];
   float *ln_g_s[kLgLayers] = {}, *ln_b_s[kLgLayers] = {}, *ln_g_c[kLgLayers] = {}, *ln_b_c[kLgLayers] = {};
   ConvW final_proj;
@@ -798,11 +799,12 @@ struct sship_lg_weights {
 };
 static void lg_weights_free(sship_lg_weights* w) {
   for (int i = 0; i < kLgLayers; ++i) {
-    for (ConvW* c : {&w->qkv[i], &w->ffn0_s[i], &w->ffn3_s[i], &w->cqkv[i], &w->ffn0_c[i], &w->ffn3_c[i]})
+    for (ConvW* c : {&w->qkv[i], &w->ffn0_s[i], &w->ffn3_s[i], &w->cqkv[i], &w->ffn0_c[i], &w->ffn3_c[i], &w->qkv_t[i], &w->cqkv_t[i]})
       free_conv(*c);
     for (float* p : {w->ln_g_s[i], w->ln_b_s[i], w->ln_g_c[i], w->ln_b_c[i]}) if (p) (void)hipFree(p);
   }
   free_conv(w->final_proj);
+  free_conv(w->final_t);
   if (w->match_w) (void)hipFree(w->match_w);
   if (w->wr) (void)hipFree(w->wr);
   delete w;
@@ -874,6 +876,11 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     const std::string pc = "transformers." + std::to_string(i) + ".cross_attn.";
     int rc = 0;
     if ((rc = lin(ps + "Wqkv", 768, 256, w->qkv[i], &qkv_map, &qkv_scale))) return bail(rc, err);
+    {
+      const Tensor* wt = find_tensor(sd, ps + "Wqkv.weight", {768, 256}, err);
+      const Tensor* bs = find_tensor(sd, ps + "Wqkv.bias", {768}, err);
+      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 768, 256, 1, 96, w->qkv_t[i], &qkv_map, &qkv_scale))) return bail(rc, g_err);
+    }
     if ((rc = ffn(ps, "out_proj", w->ffn0_s[i], w->ffn3_s[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(ps + "ffn.1.weight", 512, &w->ln_g_s[i]))) return bail(rc, err);
     if ((rc = vec(ps + "ffn.1.bias", 512, &w->ln_b_s[i]))) return bail(rc, err);
@@ -890,6 +897,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     memcpy(bcat.data() + 256, bv->data.data(), 256 * 4);
     for (int r = 0; r < 256; ++r) scat[r] = cq_scale[r];
     if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 128, w->cqkv[i], nullptr, &scat))) return bail(rc, g_err);
+    if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 64, w->cqkv_t[i], nullptr, &scat))) return bail(rc, g_err);
     if ((rc = ffn(pc, "to_out", w->ffn0_c[i], w->ffn3_c[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(pc + "ffn.1.weight", 512, &w->ln_g_c[i]))) return bail(rc, err);
     if ((rc = vec(pc + "ffn.1.bias", 512, &w->ln_b_c[i]))) return bail(rc, err);
@@ -899,6 +907,11 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     const std::string pa = "log_assignment." + std::to_string(kLgLayers - 1) + ".";
     int rc = 0;
     if ((rc = lin(pa + "final_proj", 256, 256, w->final_proj, nullptr, &fp_scale))) return bail(rc, err);
+    {
+      const Tensor* wt = find_tensor(sd, pa + "final_proj.weight", {256, 256}, err);
+      const Tensor* bs = find_tensor(sd, pa + "final_proj.bias", {256}, err);
+      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 256, 256, 1, 32, w->final_t, nullptr, &fp_scale))) return bail(rc, g_err);
+    }
     const Tensor* mw = find_tensor(sd, pa + "matchability.weight", {1, 256}, err);
     const Tensor* mb = mw ? find_tensor(sd, pa + "matchability.bias", {1}, err) : nullptr;
     if (!mb) return bail(SSHIP_ERR_IO, err);
@@ -1002,18 +1015,24 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   float* rope = lg->rope.as<float>();
   launch_lg_prep(kp, kp_stride, kp_seq_stride, lens, desc, desc_seq_stride, w->wr, (float)lg->image_w,
                  (float)lg->image_h, d, x, rope, s);
+  // 3 launches per block: [projection fused into the previous FFN's tail] -> attention -> FFN(+ next projection).
+  SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
   for (int i = 0; i < kLgLayers; ++i) {
-    // SelfBlock (both images of every pair in one launch)
-    SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[i], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
+    // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
     launch_lg_attention(q, k, vt, lens, d, false, ctx, s);
-    launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], ctx, x, T, s);
-    // CrossBlock (qk shared by both directions; sequence s attends to s^1)
-    SSHIP_HIP_CHECK(lg_linear_heads(w->cqkv[i], x, d, /*rope_segs=*/0, /*t_seg=*/1, rope, q, k, vt, s));
+    launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], ctx, x, d, &w->cqkv_t[i], true, /*rope_segs=*/0,
+                  /*t_seg=*/1, rope, q, k, vt, nullptr, nullptr, 0.f, nullptr, s);
+    // CrossBlock (qk shared by both directions; sequence s attends to s^1); its FFN emits the next layer's Wqkv,
+    // or final_proj + matchability after the last layer
     launch_lg_attention(q, q, vt, lens, d, true, ctx, s);
-    launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], ctx, x, T, s);
+    if (i + 1 < kLgLayers)
+      launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], ctx, x, d, &w->qkv_t[i + 1], true, 2, 2, rope, q, k,
+                    vt, nullptr, nullptr, 0.f, nullptr, s);
+    else
+      launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], ctx, x, d, &w->final_t, false, 0, 0, rope, q, k, vt,
+                    lg->md.as<_Float16>(), w->match_w, w->match_b, lg->logsig.as<float>(), s);
   }
-  SSHIP_HIP_CHECK(lg_linear_f16(w->final_proj, x, 256, nullptr, 0, d, lg->md.as<_Float16>(), 256, s));
-  launch_lg_matchability(x, w->match_w, w->match_b, T, lg->logsig.as<float>(), s);
+  SSHIP_HIP_CHECK(hipGetLastError());
   launch_lg_sim(lg->md.as<_Float16>(), lens, d, lg->sim.as<float>(), s);
   launch_lg_assign(lg->sim.as<float>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->max_kp, m0, ms0,
                    0.1f /* filter_threshold */, s);

@@ -85,7 +85,9 @@ hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d,
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,
                          bool cross, _Float16* ctx, hipStream_t s);
 void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
-                   _Float16* x, int tokens, hipStream_t s);
+                   _Float16* x, LgDims d, const ConvW* next, bool heads, int rope_segs, int t_seg, const float* rope,
+                   _Float16* q, _Float16* k, _Float16* vt, _Float16* out, const float* match_w, float match_b,
+                   float* logsig, hipStream_t s);
 void launch_lg_matchability(const _Float16* x, const float* w, float bias, int tokens, float* logsig, hipStream_t s);
 void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s);
 void launch_lg_assign(const float* sim, const float* logsig, const int* lens, LgDims d, float* ws, int max_kp,

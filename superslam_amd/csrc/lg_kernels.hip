@@ -303,11 +303,22 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
 //     rows); the residual add reads x from global in fp32 and writes it back in place.
 // Removes per block: 2 kernel launches and the [T,512] hidden round trip (write + read + write + read).
 // ---------------------------------------------------------------------------------------------------
+//   * NEXT_MT > 0: the projection that consumes the updated x next (CrossBlock [to_qk|to_v] after a SelfBlock FFN,
+//     the next layer's Wqkv after a CrossBlock FFN, final_proj + matchability after the last one) runs in the same
+//     launch on the 64-token tile that is already on chip: wave w owns NEXT_MT*32 output rows, K = 256, epilogue =
+//     the igemm epilogue of that projection (EpiHeads / plain fp16).
 constexpr int kFfnTok = 64, kFfnLd = 520;
+struct FfnTail {
+  IgemmArgs proj;          // epilogue arguments of the fused projection (wpack/bias/outputs/rope/np/flags/cout/H)
+  const float* match_w;    // final block only: matchability weights [256] ...
+  float match_b;
+  float* logsig;           // ... -> logsigmoid(z) per token
+};
+template <int NEXT_MT, bool HEADS>
 __global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                 const float* __restrict__ b0, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
-                                                const float* __restrict__ b3, _Float16* __restrict__ x) {
+                                                const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
   __shared__ __attribute__((aligned(16))) _Float16 s_x[kFfnTok * kFfnLd];
   __shared__ float s_red[8][kFfnTok];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
@@ -424,6 +435,7 @@ __global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx
       ac2[1] = mfma32(a0, bf1, ac2[1]);
     }
   }
+  if constexpr (NEXT_MT > 0) __syncthreads();  // all waves are done reading the hidden tile: s_x gets the new x
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int c = wave * 32 + hh * 4 + g * 8;
@@ -432,14 +444,70 @@ __global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx
     for (int n = 0; n < 2; ++n) {
       h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
       const h4_t o = *px;
-      *px = to_h4((float)o[0] + (ac2[n][4 * g + 0] + bv.x), (float)o[1] + (ac2[n][4 * g + 1] + bv.y),
-                  (float)o[2] + (ac2[n][4 * g + 2] + bv.z), (float)o[3] + (ac2[n][4 * g + 3] + bv.w));
+      const h4_t xn = to_h4((float)o[0] + (ac2[n][4 * g + 0] + bv.x), (float)o[1] + (ac2[n][4 * g + 1] + bv.y),
+                            (float)o[2] + (ac2[n][4 * g + 2] + bv.z), (float)o[3] + (ac2[n][4 * g + 3] + bv.w));
+      *px = xn;
+      if constexpr (NEXT_MT > 0) *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = xn;
+    }
+  }
+  if constexpr (NEXT_MT > 0) {
+    __syncthreads();
+    // ---- fused next projection: rows [NEXT_MT*32*wave, +NEXT_MT*32) x 64 tokens, K = 256 ----
+    f16x_t ac3[NEXT_MT][2];
+#pragma unroll
+    for (int m = 0; m < NEXT_MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
+    const _Float16* wp = tail.proj.wpack + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
+      const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
+#pragma unroll
+      for (int m = 0; m < NEXT_MT; ++m) {
+        const h8_t a = *reinterpret_cast<const h8_t*>(wp + (ks * NEXT_MT + m) * 512);
+        ac3[m][0] = mfma32(a, bf0, ac3[m][0]);
+        ac3[m][1] = mfma32(a, bf1, ac3[m][1]);
+      }
+    }
+    if constexpr (HEADS) EpiHeads::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
+    else EpiF16<false, false>::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
+    if (tail.logsig) {  // matchability head of the last block: one wave per 8 tokens
+#pragma unroll 1
+      for (int tk = wave * 8; tk < wave * 8 + 8; ++tk) {
+        const h4_t v = *reinterpret_cast<const h4_t*>(s_x + tk * kFfnLd + lane * 4);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d += (float)v[e] * tail.match_w[lane * 4 + e];
+        const float z = wave_sum(d) + tail.match_b;
+        if (lane == 0) tail.logsig[t0 + tk] = fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
+      }
     }
   }
 }
+// next == nullptr: plain FFN.  Otherwise the projection `next` (packed with ct = 32 * next_mt rows per wave) runs on
+// the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
 void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
-                   _Float16* x, int tokens, hipStream_t s) {
-  hipLaunchKernelGGL(k_lg_ffn, dim3(tokens / kFfnTok), dim3(512), 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x);
+                   _Float16* x, LgDims d, const ConvW* next, bool heads, int rope_segs, int t_seg, const float* rope,
+                   _Float16* q, _Float16* k, _Float16* vt, _Float16* out, const float* match_w, float match_b,
+                   float* logsig, hipStream_t s) {
+  const int tokens = d.S * d.NP;
+  FfnTail t{};
+  dim3 grid(tokens / kFfnTok), block(512);
+  if (!next) {
+    hipLaunchKernelGGL((k_lg_ffn<0, false>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    return;
+  }
+  t.proj = token_args(*next, x, 256, nullptr, 0, d);
+  t.proj.out0 = heads ? (void*)q : (void*)out; t.proj.out1 = k; t.proj.out2 = vt; t.proj.aux = rope;
+  t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
+  t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
+  const int mt = next->cout / 256;  // rows per wave / 32: 768 -> 3, 512 -> 2, 256 -> 1
+  if (heads && mt == 3) hipLaunchKernelGGL((k_lg_ffn<3, true>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else if (heads && mt == 2) hipLaunchKernelGGL((k_lg_ffn<2, true>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else hipLaunchKernelGGL((k_lg_ffn<1, false>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
 }
 
 // logsigmoid(matchability(x)) per token.
