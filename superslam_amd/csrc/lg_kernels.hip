@@ -198,28 +198,36 @@ __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   const int ntiles = (nk + 31) >> 5;
-  h8_t kf[4];
+  // K and V^T fragments are prefetched ONE FULL TILE ahead (loads for tile kt+4 are issued before the MFMAs and
+  // softmax of tile kt), so ~1k cycles of L2 latency hide behind a whole iteration instead of a few MFMAs.
+  h8_t kf[4], vf[2][2];
+  {
+    const int kt0 = min(wave, nt32 - 1);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)min(wave, nt32 - 1) * 4 + ks) * 512 + lane * 8);
-  for (int kt = wave; kt < ntiles; kt += 4) {
-    const int k0 = kt * 32;
-    // V^T fragments of this tile and K fragments of the wave's next tile: issued before the MFMAs that hide them
-    h8_t vf[2][2];
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)kt0 * 4 + ks) * 512 + lane * 8);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)kt * 2 + kk) * 2 + mt) * 512 + lane * 8);
+        vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)kt0 * 2 + kk) * 2 + mt) * 512 + lane * 8);
+  }
+  for (int kt = wave; kt < ntiles; kt += 4) {
+    const int k0 = kt * 32;
+    h8_t kn[4], vn[2][2];
+    const int ktn = min(kt + 4, nt32 - 1);  // clamped: the last prefetch re-reads a valid tile and is discarded
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kn[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)ktn * 4 + ks) * 512 + lane * 8);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        vn[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)ktn * 2 + kk) * 2 + mt) * 512 + lane * 8);
+    __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above this tile's MFMAs / softmax
     f16x_t st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
-    if (kt + 4 < ntiles) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)(kt + 4) * 4 + ks) * 512 + lane * 8);
-    }
     float tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -244,10 +252,14 @@ __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) pb[e] = (_Float16)p[8 * kk + e];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        o[mt] = mfma32(vf[kk][mt], pb, o[mt]);
-      }
+      for (int mt = 0; mt < 2; ++mt) o[mt] = mfma32(vf[kk][mt], pb, o[mt]);
     }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = kn[ks];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) vf[kk][mt] = vn[kk][mt];
   }
   l += __shfl_xor(l, 32, 64);
   // ---- merge the 4 key-partials ----
@@ -315,7 +327,7 @@ struct FfnTail {
   float* logsig;           // ... -> logsigmoid(z) per token
 };
 template <int NEXT_MT, bool HEADS>
-__global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
+__global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                 const float* __restrict__ b0, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
                                                 const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
@@ -338,17 +350,36 @@ __global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
   {
+    // Weight fragments stream from L2 (no reuse between waves); keep TWO groups of 8 k-steps (32 KiB per wave) in
+    // flight in registers so ~1k cycles of L2 latency are covered by the 16 MFMAs (512+ cycles) of the previous
+    // group and the co-resident wave.
     const _Float16* wp = w0p + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
-#pragma unroll 8
-    for (int ks = 0; ks < 32; ++ks) {
-      const h8_t a0 = *reinterpret_cast<const h8_t*>(wp + (ks * 2 + 0) * 512);
-      const h8_t a1 = *reinterpret_cast<const h8_t*>(wp + (ks * 2 + 1) * 512);
-      const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
-      const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
-      acc[0][0] = mfma32(a0, bf0, acc[0][0]);
-      acc[0][1] = mfma32(a0, bf1, acc[0][1]);
-      acc[1][0] = mfma32(a1, bf0, acc[1][0]);
-      acc[1][1] = mfma32(a1, bf1, acc[1][1]);
+    h8_t ab[2][8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ab[0][i][0] = *reinterpret_cast<const h8_t*>(wp + (i * 2 + 0) * 512);
+      ab[0][i][1] = *reinterpret_cast<const h8_t*>(wp + (i * 2 + 1) * 512);
+    }
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      if (grp + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          ab[(grp + 1) & 1][i][0] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * 8 + i) * 2 + 0) * 512);
+          ab[(grp + 1) & 1][i][1] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * 8 + i) * 2 + 1) * 512);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads ABOVE this group's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ks = grp * 8 + i;
+        const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
+        const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
+        acc[0][0] = mfma32(ab[grp & 1][i][0], bf0, acc[0][0]);
+        acc[0][1] = mfma32(ab[grp & 1][i][0], bf1, acc[0][1]);
+        acc[1][0] = mfma32(ab[grp & 1][i][1], bf0, acc[1][0]);
+        acc[1][1] = mfma32(ab[grp & 1][i][1], bf1, acc[1][1]);
+      }
     }
   }
   // ---- bias, LayerNorm(512) over the row dimension (spread over regs, lane^32 and the 8 waves), GELU ----
@@ -426,13 +457,24 @@ __global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx
     for (int r = 0; r < 16; ++r) ac2[n][r] = 0.f;
   {
     const _Float16* wp = w3p + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
-#pragma unroll 8
-    for (int ks = 0; ks < 32; ++ks) {
-      const h8_t a0 = *reinterpret_cast<const h8_t*>(wp + ks * 512);
-      const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
-      const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
-      ac2[0] = mfma32(a0, bf0, ac2[0]);
-      ac2[1] = mfma32(a0, bf1, ac2[1]);
+    h8_t a3[2][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a3[1][i] = *reinterpret_cast<const h8_t*>(wp + (16 + i) * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ks = grp * 16 + i;
+        const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
+        const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
+        ac2[0] = mfma32(a3[grp][i], bf0, ac2[0]);
+        ac2[1] = mfma32(a3[grp][i], bf1, ac2[1]);
+      }
     }
   }
   if constexpr (NEXT_MT > 0) __syncthreads();  // all waves are done reading the hidden tile: s_x gets the new x
@@ -461,7 +503,7 @@ __global__ __launch_bounds__(512) void k_lg_ffn(const _Float16* __restrict__ ctx
 #pragma unroll
         for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
     const _Float16* wp = tail.proj.wpack + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
-#pragma unroll 4
+#pragma unroll 16
     for (int ks = 0; ks < 16; ++ks) {
       const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
       const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
