@@ -138,8 +138,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     _lib.init(local_rank)
 
-    wdir = os.path.join(ROOT, "gpurun_out", f"bench_weights_r{rank}")
-    os.makedirs(wdir, exist_ok=True)
+    import tempfile
+
+    wdir = tempfile.mkdtemp(prefix=f"sship_bench_w{rank}_")
     spw, lgw = make_superpoint_weights(0), make_lightglue_weights(1)
     save_safetensors(spw, os.path.join(wdir, "sp.safetensors"))
     save_safetensors(lgw, os.path.join(wdir, "lg.safetensors"))

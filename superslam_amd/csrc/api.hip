@@ -450,6 +450,7 @@ struct sship_sp {
   float* b1a = nullptr;
   _Float16* w1a_frag = nullptr;  // conv1a as MFMA A fragments [2][64][8] (K = 9 taps zero-padded to 16)
   ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, cPa, cPb, cDa, cDb;
+  ConvW cDb32;  // convDb packed in 32-row blocks (one per wave of k_desc_head_gather)
   sship_pool* pool = nullptr;
   // activations (channels-last fp16), sized for (B, H, W)
   int wsB = 0, wsH = 0, wsW = 0;
@@ -500,7 +501,7 @@ static int sp_ensure(sship_sp* sp, int B, int H, int W) {
 }
 
 // encoder + both heads up to (logits, raw descriptor grid).  utils/convert_superpoint_to_onnx.py:51-64,77,88.
-static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hipStream_t s) {
+static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hipStream_t s, bool dense_desc) {
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
   // conv1a is evaluated inside conv1b's tile staging (conv_strip.hip): the 64-channel full-resolution activation
@@ -516,7 +517,8 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
   SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, s));
   SSHIP_HIP_CHECK(sp_conv1x1_f32(sp->cPb, sp->aPa.as<_Float16>(), sp->logits.as<float>(), kLogitStride, B, Hc, Wc, s));
   SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
-  SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
+  // the dense convDb grid is only materialised for the dense API; extraction evaluates convDb at the selected cells
+  if (dense_desc) SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
   g_timer.mark("sp_heads", s);
   return SSHIP_OK;
 }
@@ -570,6 +572,8 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
     const Tensor* b = w ? find_tensor(sd, std::string(l.name) + ".bias", {l.cout}, err) : nullptr;
     if (!w || !b) return fail(SSHIP_ERR_IO, err);
     if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, l.ks, l.ct, *l.dst)) return rc;
+    if (std::string(l.name) == "convDb")
+      if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, 1, 32, sp->cDb32)) return rc;
   }
   {
     const Tensor* w = find_tensor(sd, "conv1a.weight", {64, 1, 3, 3}, err);
@@ -598,7 +602,7 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
 extern "C" void sship_sp_destroy(sship_sp* sp) {
   if (!sp) return;
   (void)hipDeviceSynchronize();
-  for (ConvW* c : {&sp->c1b, &sp->c2a, &sp->c2b, &sp->c3a, &sp->c3b, &sp->c4a, &sp->c4b, &sp->cPa, &sp->cPb, &sp->cDa, &sp->cDb})
+  for (ConvW* c : {&sp->c1b, &sp->c2a, &sp->c2b, &sp->c3a, &sp->c3b, &sp->c4a, &sp->c4b, &sp->cPa, &sp->cPb, &sp->cDa, &sp->cDb, &sp->cDb32})
     free_conv(*c);
   if (sp->w1a) (void)hipFree(sp->w1a);
   if (sp->b1a) (void)hipFree(sp->b1a);
@@ -616,12 +620,12 @@ extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, 
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
   if (int rc = sp_ensure(sp, batch, h, w)) return rc;
   g_timer.begin(s);
-  if (int rc = sp_network(sp, imgs, batch, h, w, s)) return rc;
+  if (int rc = sp_network(sp, imgs, batch, h, w, s, false)) return rc;
   if (int rc = sp_select(sp, batch, h, w, nullptr, kp_out, n_out, s)) return rc;
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
-  launch_gather_hwc(true, sp->draw.as<_Float16>(), 256, Hc, Wc, (size_t)Hc * Wc * 256, sp->cell_h.as<int>(),
-                    sp->cell_w.as<int>(), n_out, 0, sp->cfg.max_keypoints, batch, static_cast<_Float16*>(desc_out), s);
+  launch_desc_head_gather(sp->cDb32, sp->aDa.as<_Float16>(), Hc, Wc, sp->cell_h.as<int>(), sp->cell_w.as<int>(), n_out,
+                          sp->cfg.max_keypoints, batch, static_cast<_Float16*>(desc_out), (size_t)sp->cfg.max_keypoints * 256, s);
   SSHIP_HIP_CHECK(hipGetLastError());
   g_timer.mark("sp_gather", s);
   return SSHIP_OK;
@@ -632,7 +636,7 @@ extern "C" int sship_sp_dense(sship_sp* sp, const uint8_t* imgs, int batch, int 
   if (!sp || !imgs || batch <= 0) return fail(SSHIP_ERR_INVALID, "sp_dense: bad arguments");
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
   if (int rc = sp_ensure(sp, batch, h, w)) return rc;
-  if (int rc = sp_network(sp, imgs, batch, h, w, s)) return rc;
+  if (int rc = sp_network(sp, imgs, batch, h, w, s, desc_grid != nullptr)) return rc;
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
   if (scores) {
@@ -713,7 +717,7 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
     launch_bgr2gray(sp->gray_in.as<uint8_t>(), B * h * w, sp->img.as<uint8_t>(), s);
   }
   g_timer.begin(s);
-  if (int rc = sp_network(sp, gray, B, h, w, s)) return rc;
+  if (int rc = sp_network(sp, gray, B, h, w, s, false)) return rc;
   if (int rc = sp_select(sp, B, h, w, nullptr, sp->kp.as<float>(), sp->n_dev.as<int>(), s)) return rc;
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
@@ -723,10 +727,10 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
     outs[b]->n = 0; outs[b]->desc_dev = nullptr;
     outs[b]->slot = sship_pool_acquire(sp->pool);  // pool_->make(n), SuperPoint.cc:721
     if (outs[b]->slot < 0) { rc_pool = SSHIP_ERR_POOL_EXHAUSTED; continue; }
-    launch_gather_hwc(true, sp->draw.as<_Float16>() + (size_t)b * Hc * Wc * 256, 256, Hc, Wc, 0,
-                      sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
-                      sp->n_dev.as<int>() + b, 0, mk, 1,
-                      static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), s);
+    launch_desc_head_gather(sp->cDb32, sp->aDa.as<_Float16>() + (size_t)b * Hc * Wc * 256, Hc, Wc,
+                            sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
+                            sp->n_dev.as<int>() + b, mk, 1,
+                            static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), 0, s);
   }
   g_timer.mark("sp_gather", s);
   SSHIP_HIP_CHECK(hipMemcpyAsync(sp->h_kp.p, sp->kp.p, (size_t)B * mk * 12, hipMemcpyDeviceToHost, s));

@@ -49,6 +49,21 @@ __device__ __forceinline__ f16x_t mfma32(h8_t a, h8_t b, f16x_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): ~14 VALU instead of ~40 for erff.  The GELU that uses
+// it is rounded to fp16 (2^-11 relative) right after, so the result is the correctly rounded exact-erf GELU in all
+// but ~1e-4 of the cases (and then off by one fp16 ulp).
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  return copysignf(fmaf(-p, e, 1.0f), x);
+}
+
 __device__ __forceinline__ h4_t to_h4(float a, float b, float c, float d) {
   h4_t v;
   v[0] = (_Float16)a; v[1] = (_Float16)b; v[2] = (_Float16)c; v[3] = (_Float16)d;

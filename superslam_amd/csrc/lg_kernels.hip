@@ -228,24 +228,30 @@ __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
-    float tmax = -INFINITY;
+    if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (key >= nk) st[r] = -INFINITY;
-      tmax = fmaxf(tmax, st[r]);
+      for (int r = 0; r < 16; ++r)
+        if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= nk) st[r] = -INFINITY;
     }
+    float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[r], st[r + 1]), fmaxf(st[r + 2], st[r + 3])));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m, tmax);
-    const float alpha = exp2f(m - m_new);
-    m = m_new;
+    // the softmax is VALU-bound at head_dim 64 (profiles/r01_v5_pmc*: 47 VALU per MFMA): rescale the 32 output
+    // accumulators only when some query's running max actually moved (exact - not the lossy defer-max trick)
+    if (__any(m_new > m)) {
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      m = m_new;
+    }
     float ls = 0.f;
     float p[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { p[r] = exp2f(st[r] - m_new); ls += p[r]; }
-    l = l * alpha + ls;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(st[r] - m); ls += p[r]; }
+    l += ls;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       h8_t pb;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float y = (acc[m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
-          o[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));
+          o[e] = 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
         }
         *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
       }
