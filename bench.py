@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=8, help="stereo pairs per step (per GPU), resident in HBM")
+    ap.add_argument("--pairs", type=int, default=32, help="stereo pairs per step (per GPU), resident in HBM")
     ap.add_argument("--max-kp", type=int, default=600, help="superpoint.max_keypoints (600 = the KITTI YAML)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -201,17 +201,23 @@ def main():
             m2 = C.c_float(0)
             _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, lid, 2 * P, H, W, 10, C.byref(m2), None))
             layer_ms[name] = round(m2.value, 4)
+        # HBM bytes per launch from the PMC passes of scripts/pmc_traffic.sh (same command, same batch); null if the
+        # committed summary was taken at another batch size
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_conv1b.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv1ab.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                if pj.get("pairs_per_step") == P:
+                    traffic = pj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "igemm_kernel<3,64,64,8,EpiF16<relu,pool>> (conv1b)", "bound": "mfma",
+        alg_bytes = 2 * P * (H * W + (H // 2) * (W // 2) * 64 * 2)   # u8 image in, pooled fp16 64-ch map out
+        roofline = {"kernel": "conv3x3_strip<64,64,pool,fuse1a> (conv1a+conv1b+maxpool, 36 % of the pair's FLOPs)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "launch_ms": round(ms.value, 4), "flops_per_launch": 2.0 * macs.value}
+                    "launch_ms": round(ms.value, 4), "flops_per_launch": 2.0 * macs.value,
+                    "algorithmic_bytes_per_launch": alg_bytes}
         flops_pair = 2 * sp_flops_per_image(H, W) + lg_flops_per_pair(args.max_kp)
         out = {
             "metric": "stereo pairs/sec (SPx2+LG) at 1376x376", "value": round(value, 2), "unit": "pairs/s",
@@ -228,6 +234,16 @@ def main():
             "stage_ms": stages, "layer_ms": layer_ms,
             "roofline": roofline,
         }
+        # single-pair latency (the reference's per-frame unit): P = 1 through the same fused call
+        fe1 = FrontEndBatch(sp, lg, 1, H, W)
+        for _ in range(5):
+            fe1.run(imgs[:2], stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            fe1.run(imgs[:2], stream)
+        torch.cuda.synchronize()
+        out["latency_ms_single_pair"] = round((time.perf_counter() - t1) / 50 * 1e3, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], args.max_kp)
         print(json.dumps(out), flush=True)
