@@ -100,13 +100,16 @@ __global__ __launch_bounds__(512) void conv3x3_strip(StripArgs p) {
       for (int i = 0; i < S_IN_IT; ++i)
         if (i < S_IN_IT - 1 || last_it_valid) rin[i] = *reinterpret_cast<const uint4*>(base + g_off[i]);
     } else {
+      // edge tiles: branch-free - load from a clamped (always valid) address, then select zero.  A conditional load
+      // makes hipcc branch around every load with its own s_waitcnt vmcnt(0): ten serialised L2 round trips.
 #pragma unroll
       for (int i = 0; i < S_IN_IT; ++i) {
         const int gy = y0 - 1 + py_[i], gx = x0 - 1 + px_[i];
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if ((i < S_IN_IT - 1 || last_it_valid) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-          v = *reinterpret_cast<const uint4*>(base + g_off[i]);
-        rin[i] = v;
+        const bool ok = (i < S_IN_IT - 1 || last_it_valid) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+        const int part8 = g_off[i] - (py_[i] * p.W + px_[i]) * CIN;
+        const uint4 v = *reinterpret_cast<const uint4*>(p.in + ((size_t)(b * p.H + cy) * p.W + cx) * CIN + chunk * 64 + part8);
+        rin[i] = ok ? v : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -227,21 +230,28 @@ __global__ __launch_bounds__(512) void conv3x3_strip(StripArgs p) {
       if (p.dbg & 4) continue;
       const _Float16* wc = s_w + chunk * (9 * 4 * MT * 512) + lane * 8;
       const _Float16* ib = s_in + ((wave * 2) * S_TWH + j) * kCP + hh * 8;
+      // 36 k-steps (9 taps x 4), fragments double-buffered in registers: the ds_reads of k-step i+1 are issued
+      // (and pinned with sched_barrier) before the MFMAs of k-step i, so LDS latency hides under the matrix pipe.
+      // hipcc on its own waits lgkmcnt(0) before every MFMA pair here.
+      h8_t fa[2][MT], fb[2][2];
+      auto load_frags = [&](int idx, int buf) {
+        const int tap = idx >> 2, ks = idx & 3, ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
+        for (int m = 0; m < MT; ++m) fa[buf][m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          h8_t a[MT];
+        for (int n = 0; n < 2; ++n)
+          fb[buf][n] = *reinterpret_cast<const h8_t*>(ib + ((n + ky) * S_TWH + kx) * kCP + ks * 16);
+      };
+      load_frags(0, 0);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
+      for (int idx = 0; idx < 36; ++idx) {
+        if (idx + 1 < 36) load_frags(idx + 1, (idx + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            const h8_t bf = *reinterpret_cast<const h8_t*>(ib + ((n + ky) * S_TWH + kx) * kCP + ks * 16);
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(a[m], bf, acc[m][n]);
-          }
-        }
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(fa[idx & 1][m], fb[idx & 1][n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- epilogue: bias + ReLU (+ 2x2 max-pool), fp16 channels-last ----
