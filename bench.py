@@ -133,8 +133,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("SUPERSLAM_HIP_DEVICE", str(local_rank))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run always go through RCCL, even at N = 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     _lib.init(local_rank)
 
@@ -162,20 +164,20 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the slowest rank defines the step time
         dt = float(t.item())
 
     n_kp = fe.n.cpu().numpy()
@@ -248,7 +250,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], args.max_kp)
         print(json.dumps(out), flush=True)
     sp.close(); lg.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

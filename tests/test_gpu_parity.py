@@ -400,3 +400,26 @@ def test_frontend_batch_equals_separate_calls(sp, lg):
         np.testing.assert_array_equal(fe.matches0[p, :n0].cpu().numpy(), res.matches0)
         np.testing.assert_allclose(fe.mscores0[p, :n0].cpu().numpy(), res.mscores0, atol=1e-6)
         assert (fe.matches0[p, n0:].cpu().numpy() == -1).all()
+
+
+def test_offline_extraction_sharded_equals_direct(sp, hip):
+    """Config-3 semantics on one GPU: frames processed in shards (two 'ranks' emulated sequentially) and
+    concatenated in unit order equal the one-shot batch result bit-for-bit (units are independent)."""
+    from superslam_amd.shard import shard_block
+    from superslam_amd.synth import make_frame
+
+    base = make_frame(120, 160, 77)
+    frames = np.stack([np.roll(base, (f * 7, f * 13), axis=(0, 1)) for f in range(5)])
+    full_d, full_k, full_n = sp.extract_batch_device(dev(frames[:2]))
+    torch.cuda.synchronize()
+    parts = []
+    for r in range(2):
+        a, b = shard_block(2, r, 2)
+        d, k, n = sp.extract_batch_device(dev(frames[a:b]))
+        torch.cuda.synchronize()
+        parts.append((d.clone(), k.clone(), n.clone()))
+    assert torch.equal(torch.cat([p[2] for p in parts]), full_n)
+    for i in range(2):
+        nn = int(full_n[i])
+        assert torch.equal(torch.cat([p[1] for p in parts])[i, :nn], full_k[i, :nn])
+        assert torch.equal(torch.cat([p[0] for p in parts])[i, :nn], full_d[i, :nn])
