@@ -500,23 +500,40 @@ static int sp_ensure(sship_sp* sp, int B, int H, int W) {
   return SSHIP_OK;
 }
 
+// 3x3 conv dispatch.  Measured at P = 32 (profiles/r01_pp_vs_strip.txt): the ping-pong kernel (conv_pp.hip) wins on the
+// fused conv1a+conv1b layer (2.09 vs 2.19 ms) and loses on the others (their data role - 43.5 KB of HBM input per
+// tile - is longer than the MFMA role), so the default is  conv1ab -> ping-pong, the rest -> lock-step strip kernel.
+// SUPERSLAM_HIP_CONV = pp | strip forces one kernel everywhere (A/B runs).
+static int conv_mode() {  // 0 hybrid, 1 all ping-pong, 2 all strip
+  static const int v = [] {
+    const char* e = getenv("SUPERSLAM_HIP_CONV");
+    if (!e) return 0;
+    return std::string(e) == "pp" ? 1 : (std::string(e) == "strip" ? 2 : 0);
+  }();
+  return v;
+}
+static hipError_t conv3(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s) {
+  return conv_mode() == 1 ? sp_conv3x3_pp(w, in, out, B, H, W, pool, s) : sp_conv3x3_strip(w, in, out, B, H, W, pool, s);
+}
+static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s);
+
 // encoder + both heads up to (logits, raw descriptor grid).  utils/convert_superpoint_to_onnx.py:51-64,77,88.
 static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hipStream_t s, bool dense_desc) {
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
   // conv1a is evaluated inside conv1b's tile staging (conv_strip.hip): the 64-channel full-resolution activation
   // never exists in HBM.
-  SSHIP_HIP_CHECK(sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, s));
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, s));
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c4a, sp->a3b.as<_Float16>(), sp->a4a.as<_Float16>(), B, Hc, Wc, false, s));
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->c4b, sp->a4a.as<_Float16>(), sp->a4b.as<_Float16>(), B, Hc, Wc, false, s));
+  SSHIP_HIP_CHECK(conv1ab(sp, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
+  SSHIP_HIP_CHECK(conv3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));
+  SSHIP_HIP_CHECK(conv3(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, s));
+  SSHIP_HIP_CHECK(conv3(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, s));
+  SSHIP_HIP_CHECK(conv3(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, s));
+  SSHIP_HIP_CHECK(conv3(sp->c4a, sp->a3b.as<_Float16>(), sp->a4a.as<_Float16>(), B, Hc, Wc, false, s));
+  SSHIP_HIP_CHECK(conv3(sp->c4b, sp->a4a.as<_Float16>(), sp->a4b.as<_Float16>(), B, Hc, Wc, false, s));
   g_timer.mark("sp_encoder", s);
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, s));
+  SSHIP_HIP_CHECK(conv3(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, s));
   SSHIP_HIP_CHECK(sp_conv1x1_f32(sp->cPb, sp->aPa.as<_Float16>(), sp->logits.as<float>(), kLogitStride, B, Hc, Wc, s));
-  SSHIP_HIP_CHECK(sp_conv3x3_strip(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
+  SSHIP_HIP_CHECK(conv3(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
   // the dense convDb grid is only materialised for the dense API; extraction evaluates convDb at the selected cells
   if (dense_desc) SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
   g_timer.mark("sp_heads", s);
@@ -545,6 +562,11 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
   SSHIP_HIP_CHECK(hipGetLastError());
   g_timer.mark("sp_select", s);
   return SSHIP_OK;
+}
+
+static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s) {
+  return conv_mode() != 2 ? sp_conv1ab_pp(sp->c1b, sp->w1a_frag, sp->b1a, img, out, B, H, W, s)
+                          : sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, img, out, B, H, W, s);
 }
 
 extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
@@ -665,16 +687,16 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
   auto run = [&]() -> hipError_t {
     switch (layer) {
       case 0: launch_conv1a(sp->img.as<uint8_t>(), sp->w1a, sp->b1a, a1a, batch, h, w, s); return hipGetLastError();  // stand-alone (not on the path)
-      case 1: return sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, sp->img.as<uint8_t>(), a1b, batch, h, w, s);
-      case 2: return sp_conv3x3_strip(sp->c2a, a1b, a2a, batch, H2, W2, false, s);
-      case 3: return sp_conv3x3_strip(sp->c2b, a2a, a2b, batch, H2, W2, true, s);
-      case 4: return sp_conv3x3_strip(sp->c3a, a2b, a3a, batch, H4, W4, false, s);
-      case 5: return sp_conv3x3_strip(sp->c3b, a3a, a3b, batch, H4, W4, true, s);
-      case 6: return sp_conv3x3_strip(sp->c4a, a3b, a4a, batch, Hc, Wc, false, s);
-      case 7: return sp_conv3x3_strip(sp->c4b, a4a, a4b, batch, Hc, Wc, false, s);
-      case 8: return sp_conv3x3_strip(sp->cPa, a4b, aPa, batch, Hc, Wc, false, s);
+      case 1: return conv1ab(sp, sp->img.as<uint8_t>(), a1b, batch, h, w, s);
+      case 2: return conv3(sp->c2a, a1b, a2a, batch, H2, W2, false, s);
+      case 3: return conv3(sp->c2b, a2a, a2b, batch, H2, W2, true, s);
+      case 4: return conv3(sp->c3a, a2b, a3a, batch, H4, W4, false, s);
+      case 5: return conv3(sp->c3b, a3a, a3b, batch, H4, W4, true, s);
+      case 6: return conv3(sp->c4a, a3b, a4a, batch, Hc, Wc, false, s);
+      case 7: return conv3(sp->c4b, a4a, a4b, batch, Hc, Wc, false, s);
+      case 8: return conv3(sp->cPa, a4b, aPa, batch, Hc, Wc, false, s);
       case 9: return sp_conv1x1_f32(sp->cPb, aPa, sp->logits.as<float>(), kLogitStride, batch, Hc, Wc, s);
-      case 10: return sp_conv3x3_strip(sp->cDa, a4b, aDa, batch, Hc, Wc, false, s);
+      case 10: return conv3(sp->cDa, a4b, aDa, batch, Hc, Wc, false, s);
       default: return sp_conv1x1_f16(sp->cDb, aDa, sp->draw.as<_Float16>(), batch, Hc, Wc, s);
     }
   };

@@ -1,0 +1,397 @@
+// Ping-pong 3x3 convolution for SuperPoint (utils/convert_superpoint_to_onnx.py:38-49) - the production conv kernel.
+//
+// The strip kernel (conv_strip.hip) runs ONE workgroup per CU (72 KiB of weights + the input tile fill the LDS) and
+// its 8 waves move through  stage -> MFMA -> epilogue  in lock-step, so the matrix pipe idles while they all do
+// VALU / LDS / VMEM work (ablation in DESIGN.md: epilogue 19-30 %, conv1a phase 12 %, MFMA loop itself ~85 % efficient).
+// CDNA4 puts two waves of a 512-thread workgroup on every SIMD; here they get complementary roles:
+//
+//   group g = wave >> 2 (waves g*4 .. g*4+3: one per SIMD) owns its own 8 x 32 pixel tile stream and its own LDS input
+//   buffer.  In half-step s, group (s & 1) runs the uninterrupted 144-MFMA loop of its current tile while the other
+//   group - on the same SIMDs - writes out the epilogue of its previous tile, stages its next tile into LDS and
+//   issues the prefetch for the one after.  One workgroup barrier per half-step; the matrix pipe of every SIMD is
+//   fed by one wave at a time, the other wave's VALU/LDS/VMEM work rides in its shadow.
+//
+// LDS: 2 x 43,520 B input tiles (10 x 34 px x 64 ch, NO padding: a 16-byte-unit XOR swizzle  unit ^= (px >> 1) & 7
+// makes every ds_read_b128 lane group hit 16 distinct slots) + 73,728 B weights = 160,768 B.
+//   CIN = 64 : CT = 64 (MT = 2);   CIN = 128: CT = 32 (MT = 1), two 64-channel chunks per tile (two MFMA half-steps).
+//   FUSE1A (conv1b): the tile is produced by conv1a on the matrix cores (K = 9 -> 16) from u8 pixels that each lane
+//   prefetched into registers two half-steps earlier; no LDS patch, no extra barrier.
+#include <cstdlib>
+
+#include "igemm.h"
+#include "kernels.h"
+
+namespace sship {
+
+struct PpArgs {
+  const _Float16* in;    // channels-last fp16 [B,H,W,CIN]   (unused when FUSE1A)
+  const uint8_t* img;    // u8 [B,H,W]                        (FUSE1A)
+  const _Float16* w1a;   // conv1a A fragments [2][64][8] fp16 (FUSE1A)
+  const float* b1a;      // conv1a bias [64]                  (FUSE1A)
+  const _Float16* wpack; // packed weights [cb][chunk][tap][kstep][mt][lane][8]
+  const float* bias;
+  _Float16* out;
+  int B, H, W, cout;
+  int dbg;  // ablation (SSHIP_PP_DBG): 1 skip staging, 2 skip epilogue, 4 skip MFMA loop, 8 skip prefetch
+};
+
+constexpr int P_TH = 8, P_TW = 32, P_THH = 10, P_TWH = 34;
+constexpr int P_IN_HALFS = P_THH * P_TWH * 64;      // 21,760 halfs = 43,520 B
+constexpr int P_W_HALFS = 36864;                    // 72 KiB
+constexpr int P_IN_UNITS = P_THH * P_TWH * 8;       // 2720 sixteen-byte units
+constexpr int P_IN_IT = (P_IN_UNITS + 255) / 256;   // 11 per thread of a 256-thread group
+constexpr int P_NT1A = (P_THH * P_TWH + 31) / 32;   // 11 conv1a N-tiles of 32 halo pixels
+
+// swizzled LDS offset (halfs) of 16-byte unit `unit` of halo pixel (row, col)
+__device__ __forceinline__ int pp_lds(int row, int col, int unit) {
+  return (row * P_TWH + col) * 64 + ((unit ^ ((col >> 1) & 7)) << 3);
+}
+
+template <int CIN, int CT, bool POOL, bool FUSE1A>
+__global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
+  constexpr int MT = CT / 32, NCHUNK = CIN / 64;
+  static_assert(NCHUNK * 9 * 4 * MT * 512 == P_W_HALFS, "weights must fill exactly 72 KiB");
+  static_assert(!FUSE1A || CIN == 64, "conv1a fusion feeds a 64-channel layer");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  _Float16* s_w = reinterpret_cast<_Float16*>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);  // wave-uniform role selector (keeps the role branch scalar)
+  const int gw = wave & 3, gt = tid & 255;
+  _Float16* my_in = s_w + P_W_HALFS + grp * P_IN_HALFS;
+
+  const int tiles_x = (p.W + P_TW - 1) / P_TW, tiles_y = (p.H + P_TH - 1) / P_TH;
+  const int ntiles = p.B * tiles_x * tiles_y;
+  const int cb = blockIdx.y;
+  const int t_begin = (int)((long long)blockIdx.x * ntiles / gridDim.x);
+  const int t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  const int n_wg = t_end - t_begin;
+  if (n_wg <= 0) return;
+  // group g takes tiles t_begin + g, t_begin + g + 2, ...; a work item is (tile, 64-channel chunk)
+  const int nw0 = ((n_wg + 1) >> 1) * NCHUNK, nw1 = (n_wg >> 1) * NCHUNK;
+  const int NW = grp ? nw1 : nw0;
+  const int s_end = max(2 * nw0 - 1, 2 * nw1);  // last half-step in which some group still has an epilogue to write
+
+  {  // weights: once per workgroup, all 512 threads
+    const _Float16* wsrc = p.wpack + (size_t)cb * P_W_HALFS;
+    for (int u = tid; u < P_W_HALFS / 8; u += 512)
+      *reinterpret_cast<uint4*>(s_w + u * 8) = *reinterpret_cast<const uint4*>(wsrc + u * 8);
+  }
+  // bias of this workgroup's CT channels lives in LDS (registers are the scarce resource here: acc 64 + prefetch 44 +
+  // fragment double buffers 32 per lane), read back as float4 in the epilogue
+  float* s_bias = reinterpret_cast<float*>(s_w + P_W_HALFS + 2 * P_IN_HALFS);
+  if (tid < CT) s_bias[tid] = p.bias[cb * CT + tid];
+  if constexpr (FUSE1A) { if (tid >= 64 && tid < 128) s_bias[tid] = p.b1a[tid - 64]; }  // conv1a bias at s_bias[64..127]
+  // fragment-read offsets: B fragment of (row n + ky, col j + kx), k-step ks -> unit (2 ks + hh) ^ ((j + kx) >> 1 & 7)
+  int boff[3][4];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) boff[kx][ks] = (j + kx) * 64 + (((2 * ks + hh) ^ (((j + kx) >> 1) & 7)) << 3);
+
+  auto tile_of = [&](int item) { return t_begin + grp + 2 * (item / NCHUNK); };
+  auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % tiles_x;
+    const int r = t / tiles_x;
+    x0 = tx * P_TW; y0 = (r % tiles_y) * P_TH; b = r / tiles_y;
+  };
+
+  // ---------------- staging (plain variant): global -> registers (prefetch) -> LDS ----------------
+  uint4 rin[FUSE1A ? 1 : P_IN_IT];
+  auto prefetch_in = [&](int item) {
+    if constexpr (!FUSE1A) {
+      int b, y0, x0;
+      tile_coords(tile_of(item), b, y0, x0);
+      const int chunk = item % NCHUNK;
+      int gtv = gt;
+      asm volatile("" : "+v"(gtv));  // opaque: keeps the per-iteration geometry from being hoisted into ~50 live VGPRs
+      const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
+      const _Float16* base = p.in + ((size_t)(b * p.H + (y0 - 1)) * p.W + (x0 - 1)) * CIN + chunk * 64;
+#pragma unroll
+      for (int i = 0; i < P_IN_IT; ++i) {
+        const int u = gtv + i * 256;
+        const int pix = u >> 3, part = u & 7;
+        const int py = pix / P_TWH, px = pix - py * P_TWH;
+        if (interior) {
+          if (i < P_IN_IT - 1 || u < P_IN_UNITS) rin[i] = *reinterpret_cast<const uint4*>(base + (py * p.W + px) * CIN + part * 8);
+        } else {  // branch-free: clamped address + select (a conditional load would serialise behind vmcnt(0))
+          const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+          const bool ok = u < P_IN_UNITS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+          const uint4 v = *reinterpret_cast<const uint4*>(p.in + ((size_t)(b * p.H + cy) * p.W + cx) * CIN + chunk * 64 + part * 8);
+          rin[i] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto stage_in = [&]() {
+    if constexpr (!FUSE1A) {
+      int gtv = gt;
+      asm volatile("" : "+v"(gtv));
+#pragma unroll
+      for (int i = 0; i < P_IN_IT; ++i) {
+        const int u = gtv + i * 256;
+        const int pix = u >> 3, part = u & 7;
+        const int py = pix / P_TWH, px = pix - py * P_TWH;
+        if (i < P_IN_IT - 1 || u < P_IN_UNITS) *reinterpret_cast<uint4*>(my_in + pp_lds(py, px, part)) = rin[i];
+      }
+    }
+  };
+  // ---------------- staging (FUSE1A): u8 pixels -> registers (prefetch) -> conv1a MFMA -> LDS ----------------
+  // wave gw of the group owns conv1a N-tiles gw, gw + 4, gw + 8 (< 11); lane (j, hh) of N-tile nt is halo pixel
+  // q = 32 nt + j and needs taps 8 hh .. 8 hh + 7 of its 3x3 patch (taps 9..15 are the zero padding of K).
+  constexpr int NT_W = 3;
+  unsigned rp[FUSE1A ? NT_W : 1][3];  // per N-tile: the pixel's 3x3 patch as 3 dwords (bytes 0..2 of patch row r)
+  auto prefetch_u8 = [&](int item) {
+    if constexpr (FUSE1A) {
+      int b, y0, x0;
+      tile_coords(tile_of(item), b, y0, x0);
+      const uint8_t* im = p.img + (size_t)b * p.H * p.W;
+      int jv = j;
+      asm volatile("" : "+v"(jv));
+      // interior: the whole 12 x 36 patch (+3 bytes of dword over-read) lies inside the image -> three unaligned
+      // dword loads per pixel, no clamping (24 clamped byte loads per lane made this the longest part of the step)
+      const bool interior = y0 >= 2 && y0 + P_TH + 2 <= p.H && x0 >= 2 && x0 + P_TW + 2 + 3 <= p.W;
+#pragma unroll
+      for (int k = 0; k < NT_W; ++k) {
+        const int nt = gw + 4 * k;
+        const int q = min(nt * 32 + jv, P_THH * P_TWH - 1);
+        const int py = q / P_TWH, px = q - py * P_TWH;
+        if (interior) {
+          const uint8_t* pp = im + (size_t)(y0 - 2 + py) * p.W + (x0 - 2 + px);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            unsigned v;
+            __builtin_memcpy(&v, pp + (size_t)r * p.W, 4);  // unaligned global_load_dword
+            rp[k][r] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            unsigned v = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int gy = y0 - 2 + py + r, gx = x0 - 2 + px + c;
+              const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+              const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+              const unsigned bv = im[(size_t)cy * p.W + cx];
+              v |= (ok ? bv : 0u) << (8 * c);
+            }
+            rp[k][r] = v;
+          }
+        }
+      }
+    }
+  };
+  auto stage_conv1a = [&](int item) {
+    if constexpr (FUSE1A) {
+      int b, y0, x0;
+      tile_coords(tile_of(item), b, y0, x0);
+      const h8_t a0 = *reinterpret_cast<const h8_t*>(p.w1a + lane * 8);
+      const h8_t a1 = *reinterpret_cast<const h8_t*>(p.w1a + 512 + lane * 8);
+#pragma unroll
+      for (int k = 0; k < NT_W; ++k) {
+        const int nt = gw + 4 * k;
+        if (nt >= P_NT1A) continue;
+        // taps (r, c) = byte c of dword r; cv convertTo: float(u8) * (1/255), then the engine's fp16 input
+        _Float16 t[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) t[r][c] = (_Float16)((float)((rp[k][r] >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
+        h8_t bf;  // lanes hh = 0: taps 0..7; lanes hh = 1: tap 8 and the zero padding of K = 9 -> 16
+        bf[0] = hh ? t[2][2] : t[0][0];
+        bf[1] = hh ? (_Float16)0.f : t[0][1];
+        bf[2] = hh ? (_Float16)0.f : t[0][2];
+        bf[3] = hh ? (_Float16)0.f : t[1][0];
+        bf[4] = hh ? (_Float16)0.f : t[1][1];
+        bf[5] = hh ? (_Float16)0.f : t[1][2];
+        bf[6] = hh ? (_Float16)0.f : t[2][0];
+        bf[7] = hh ? (_Float16)0.f : t[2][1];
+        f16x_t d0, d1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+        d0 = mfma32(a0, bf, d0);
+        d1 = mfma32(a1, bf, d1);
+        const int q = nt * 32 + j;
+        const int py = q / P_TWH, px = q - py * P_TWH;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;  // conv1b's zero padding is on conv1a's OUTPUT
+        if (q < P_THH * P_TWH) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = hh * 4 + g * 8;  // channels c..c+3 (M-tile 0) and 32 + c .. (M-tile 1): 8-byte half units
+            const float4 b0v = *reinterpret_cast<const float4*>(s_bias + 64 + c);
+            const float4 b1v = *reinterpret_cast<const float4*>(s_bias + 64 + 32 + c);
+            h4_t o0 = to_h4(fmaxf(d0[4 * g] + b0v.x, 0.f), fmaxf(d0[4 * g + 1] + b0v.y, 0.f), fmaxf(d0[4 * g + 2] + b0v.z, 0.f),
+                            fmaxf(d0[4 * g + 3] + b0v.w, 0.f));
+            h4_t o1 = to_h4(fmaxf(d1[4 * g] + b1v.x, 0.f), fmaxf(d1[4 * g + 1] + b1v.y, 0.f), fmaxf(d1[4 * g + 2] + b1v.z, 0.f),
+                            fmaxf(d1[4 * g + 3] + b1v.w, 0.f));
+            if (!inside) { o0 = to_h4(0.f, 0.f, 0.f, 0.f); o1 = o0; }
+            *reinterpret_cast<h4_t*>(my_in + pp_lds(py, px, c >> 3) + (c & 7)) = o0;
+            *reinterpret_cast<h4_t*>(my_in + pp_lds(py, px, (32 + c) >> 3) + (c & 7)) = o1;
+          }
+        }
+      }
+    }
+  };
+
+  f16x_t acc[MT][2];
+  // ---------------- MFMA half-step: 36 k-steps of one 64-channel chunk, fragments double-buffered ----------------
+  auto mfma_item = [&](int item) {
+    const int chunk = item % NCHUNK;
+    if (chunk == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    }
+    const _Float16* wc = s_w + chunk * (9 * 4 * MT * 512) + lane * 8;
+    const _Float16* ib = my_in + (gw * 2) * P_TWH * 64;
+    // one wave per SIMD feeds the matrix pipe here, so LDS latency must be covered by this wave alone: fragments are
+    // triple-buffered, the ds_reads of k-step i+2 are issued (and pinned) before the MFMAs of k-step i.
+    h8_t fa[3][MT], fb[3][2];
+    auto load_frags = [&](int idx, int buf) {
+      const int tap = idx >> 2, ks = idx & 3, ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[buf][m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) fb[buf][n] = *reinterpret_cast<const h8_t*>(ib + (n + ky) * P_TWH * 64 + boff[kx][ks]);
+    };
+    load_frags(0, 0);
+    load_frags(1, 1);
+#pragma unroll
+    for (int idx = 0; idx < 36; ++idx) {
+      if (idx + 2 < 36) load_frags(idx + 2, (idx + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(fa[idx % 3][m], fb[idx % 3][n], acc[m][n]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // ---------------- epilogue: bias + ReLU (+ 2x2 max-pool) -> fp16 channels-last, 16-byte stores ----------------
+  auto epilogue = [&](int item) {
+    int b, y0, x0;
+    tile_coords(tile_of(item), b, y0, x0);
+    const int yb = y0 + gw * 2, x = x0 + j;
+    auto pack2 = [](float lo, float hi) -> unsigned {
+      const h2_t v = {(_Float16)lo, (_Float16)hi};
+      return *reinterpret_cast<const unsigned*>(&v);
+    };
+    auto store_pair = [&](_Float16* pix, int m, int g, const float (&q0)[4], const float (&q1)[4], bool ok) {
+      const unsigned a0 = pack2(q0[0], q0[1]), a1 = pack2(q0[2], q0[3]);
+      const unsigned b0 = pack2(q1[0], q1[1]), b1 = pack2(q1[2], q1[3]);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      if (ok) *reinterpret_cast<uint4*>(pix + cb * CT + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    };
+    if constexpr (!POOL) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int y = yb + n;
+        const bool ok = y < p.H && x < p.W;
+        _Float16* pix = p.out + ((size_t)(b * p.H + y) * p.W + x) * p.cout;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            float q0[4], q1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              q0[e] = fmaxf(acc[m][n][4 * g + e] + s_bias[m * 32 + hh * 4 + g * 8 + e], 0.f);
+              q1[e] = fmaxf(acc[m][n][4 * (g + 1) + e] + s_bias[m * 32 + hh * 4 + (g + 1) * 8 + e], 0.f);
+            }
+            store_pair(pix, m, g, q0, q1, ok);
+          }
+      }
+    } else {
+      const int Ho = p.H >> 1, Wo = p.W >> 1;
+      const int yo = yb >> 1, xo = x >> 1;
+      const bool ok = !(x & 1) && yo < Ho && xo < Wo;
+      _Float16* pix = p.out + ((size_t)(b * Ho + yo) * Wo + xo) * p.cout;
+      auto pool4 = [&](int m, int g, float (&q)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float tt = fmaxf(acc[m][0][4 * g + e], acc[m][1][4 * g + e]);
+          const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tt), 0xB1, 0xF, 0xF, false));
+          q[e] = fmaxf(fmaxf(tt, nb) + s_bias[m * 32 + hh * 4 + g * 8 + e], 0.f);
+        }
+      };
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          float q0[4], q1[4];
+          pool4(m, g, q0);
+          pool4(m, g + 1, q1);
+          store_pair(pix, m, g, q0, q1, ok);
+        }
+    }
+  };
+
+  // item w of group g: staged in half-step 2w + g - 1, MFMA in 2w + g, epilogue (after its last chunk) in 2w + g + 1
+  if (NW > 0) { if constexpr (FUSE1A) prefetch_u8(0); else prefetch_in(0); }
+#pragma unroll 1
+  for (int s = -1; s <= s_end; ++s) {
+    if (((s + 1) & 1) == grp) {
+      // ---- data-movement role: epilogue of the item whose MFMA just finished, stage the next item, prefetch ----
+      const int w_done = (s - 1 - grp) >> 1;  // item whose MFMA ran in half-step s - 1
+      if (s - 1 - grp >= 0 && w_done < NW && (w_done % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w_done);
+      const int w_next = (s + 1 - grp) >> 1;  // item whose MFMA runs in half-step s + 1
+      if (w_next < NW) {
+        if (!(p.dbg & 1)) { if constexpr (FUSE1A) stage_conv1a(w_next); else stage_in(); }
+        if (w_next + 1 < NW && !(p.dbg & 8)) { if constexpr (FUSE1A) prefetch_u8(w_next + 1); else prefetch_in(w_next + 1); }
+      }
+    } else {
+      const int w = (s - grp) >> 1;
+      if (s - grp >= 0 && w < NW && !(p.dbg & 4)) mfma_item(w);
+    }
+    __syncthreads();
+  }
+}
+
+template <int CIN, int CT, bool POOL, bool FUSE1A>
+static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
+  PpArgs a = a_in;
+  static const int dbg = getenv("SSHIP_PP_DBG") ? atoi(getenv("SSHIP_PP_DBG")) : 0;
+  a.dbg = dbg;
+  constexpr size_t smem = (size_t)(2 * P_IN_HALFS + P_W_HALFS) * 2 + 128 * 4;
+  static_assert(smem <= 163840, "LDS budget");
+  auto kern = conv3x3_pp<CIN, CT, POOL, FUSE1A>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int ncb = a.cout / CT;
+  const int ntiles = a.B * ((a.W + P_TW - 1) / P_TW) * ((a.H + P_TH - 1) / P_TH);
+  int gx = 256 / ncb;  // one persistent workgroup per CU
+  if (gx < 1) gx = 1;
+  if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;  // every workgroup should feed both of its wave groups
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(kern, dim3(gx, ncb), dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s) {
+  PpArgs a{};
+  a.in = in; a.wpack = w.w; a.bias = w.bias; a.out = out; a.B = B; a.H = H; a.W = W; a.cout = w.cout;
+  if (w.cin == 64 && w.ct == 64) return pool ? launch_pp<64, 64, true, false>(a, s) : launch_pp<64, 64, false, false>(a, s);
+  if (w.cin == 128 && w.ct == 32) return pool ? launch_pp<128, 32, true, false>(a, s) : launch_pp<128, 32, false, false>(a, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t sp_conv1ab_pp(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img, _Float16* out,
+                         int B, int H, int W, hipStream_t s) {
+  PpArgs a{};
+  a.img = img; a.w1a = w1a_frag; a.b1a = b1a; a.wpack = w1b.w; a.bias = w1b.bias; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.cout = w1b.cout;
+  if (w1b.cin != 64 || w1b.ct != 64) return hipErrorInvalidValue;
+  return launch_pp<64, 64, true, true>(a, s);
+}
+
+}  // namespace sship
