@@ -2,6 +2,9 @@
 // Token streams are channels-last fp16 [S*NP][256]; S = 2*pairs sequences (2p = set 0, 2p+1 = set 1 of pair p),
 // NP = padded tokens per sequence.  Per-sequence valid lengths live in device memory (`lens`) so the whole
 // matcher runs without a host round trip after SuperPoint's on-device top-k.
+#include <cstdlib>
+#include <type_traits>
+
 #include "igemm.h"
 #include "kernels.h"
 
@@ -327,6 +330,9 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
 //     the igemm epilogue of that projection (EpiHeads / plain fp16).
 constexpr int kFfnTok = 64, kFfnLd = 520;
 struct FfnTail {
+  int dbg;                                  // ablation (SSHIP_FFN_DBG): 1 skip ffn.0 MFMAs, 2 skip LN/GELU math, 4 skip ffn.3, 8 skip tail
+  int copies0, copies3, copiesp;            // weight replicas (workgroup b reads replica b % copies)
+  size_t stride0, stride3, stridep;         // halfs between replicas
   IgemmArgs proj;          // epilogue arguments of the fused projection (wpack/bias/outputs/rope/np/flags/cout/H)
   const float* match_w;    // final block only: matchability weights [256] ...
   float match_b;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   for (int u = tid; u < kFfnTok * 64; u += 512) {
     const int tok = u >> 6, part = u & 63;
     const _Float16* src = part < 32 ? x + (t0 + tok) * 256 + part * 8 : ctx + (t0 + tok) * 256 + (part - 32) * 8;
-    *reinterpret_cast<uint4*>(s_x + tok * kFfnLd + part * 8) = *reinterpret_cast<const uint4*>(src);
+    *reinterpret_cast<uint4*>(s_x + tok * kFfnLd + part * 8) = (tail.dbg & 16) ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(src);
   }
   __syncthreads();
   // ---- ffn.0 : rows [64 wave, +64) x 64 tokens, K = 512 ----
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     // Weight fragments stream from L2 (no reuse between waves); keep TWO groups of 8 k-steps (32 KiB per wave) in
     // flight in registers so ~1k cycles of L2 latency are covered by the 16 MFMAs (512+ cycles) of the previous
     // group and the co-resident wave.
-    const _Float16* wp = w0p + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
+    const _Float16* wp = w0p + (blockIdx.x % tail.copies0) * tail.stride0 + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
     h8_t ab[2][8][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -368,6 +374,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     }
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
+      if (tail.dbg & 1) break;
       if (grp + 1 < 4) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float y = (acc[m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
-          o[e] = 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
+          o[e] = (tail.dbg & 2) ? y : 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
         }
         *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
       }
@@ -462,12 +469,13 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) ac2[n][r] = 0.f;
   {
-    const _Float16* wp = w3p + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
+    const _Float16* wp = w3p + (blockIdx.x % tail.copies3) * tail.stride3 + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
     h8_t a3[2][16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
+      if (tail.dbg & 4) break;
       if (grp == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) a3[1][i] = *reinterpret_cast<const h8_t*>(wp + (16 + i) * 512);
@@ -491,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
+      if (tail.dbg & 64) continue;
       const h4_t o = *px;
       const h4_t xn = to_h4((float)o[0] + (ac2[n][4 * g + 0] + bv.x), (float)o[1] + (ac2[n][4 * g + 1] + bv.y),
                             (float)o[2] + (ac2[n][4 * g + 2] + bv.z), (float)o[3] + (ac2[n][4 * g + 3] + bv.w));
@@ -508,20 +517,75 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
-    const _Float16* wp = tail.proj.wpack + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
+    const _Float16* wp = tail.proj.wpack + (blockIdx.x % tail.copiesp) * tail.stridep + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
+    // M-tiles of the V segment run with SWAPPED operands (A = token tile, B = weights): the accumulator then holds
+    // D[token][channel] with lane = channel and 8 consecutive registers = the 8 keys of one PV A-fragment unit, so V^T is
+    // written in fragment order with one 16-byte store per lane (the 2-byte transposing stores it replaces were ~16x
+    // write-amplified and dominated the kernel's non-MFMA time).
+    const int t_seg = (tail.proj.flags >> 4) & 0xf;
+    // which of this wave's M-tiles belong to the V segment is wave-uniform; the loop is instantiated per pattern
+    // (VMASK bit m = tile m is V) so its body stays branch-free: self Wqkv (3 tiles/wave): 000, 110 (wave 5), 111;
+    // cross [to_qk|to_v] (2 tiles/wave): 00, 11.
+    auto run_tail = [&](auto vmask_c) {
+      constexpr int VMASK = decltype(vmask_c)::value;
 #pragma unroll 16
-    for (int ks = 0; ks < 16; ++ks) {
-      const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
-      const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
+      for (int ks = 0; ks < 16; ++ks) {
+        if (tail.dbg & 8) break;
+        const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
+        const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
 #pragma unroll
-      for (int m = 0; m < NEXT_MT; ++m) {
-        const h8_t a = *reinterpret_cast<const h8_t*>(wp + (ks * NEXT_MT + m) * 512);
-        ac3[m][0] = mfma32(a, bf0, ac3[m][0]);
-        ac3[m][1] = mfma32(a, bf1, ac3[m][1]);
+        for (int m = 0; m < NEXT_MT; ++m) {
+          const h8_t a = *reinterpret_cast<const h8_t*>(wp + (ks * NEXT_MT + m) * 512);
+          if ((VMASK >> m) & 1) {
+            ac3[m][0] = mfma32(bf0, a, ac3[m][0]);
+            ac3[m][1] = mfma32(bf1, a, ac3[m][1]);
+          } else {
+            ac3[m][0] = mfma32(a, bf0, ac3[m][0]);
+            ac3[m][1] = mfma32(a, bf1, ac3[m][1]);
+          }
+        }
       }
+      if (tail.dbg & 32) return;
+      if constexpr (HEADS) {
+        const int NP = tail.proj.np, nt32 = NP >> 5;
+#pragma unroll
+        for (int m = 0; m < NEXT_MT; ++m) {
+          const int R0 = (wave * NEXT_MT + m) * 32;  // first output row of this M-tile
+          if ((VMASK >> m) & 1) {
+            const int hd = (R0 >> 6) & 3, mth = (R0 >> 5) & 1;  // head, 32-channel half of the head
+            const float bv = tail.proj.bias[R0 + j];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              const size_t token = t0 + n * 32;
+              const int sq = (int)(token / NP), kt = (int)(token - (size_t)sq * NP) >> 5;
+              _Float16* dst = static_cast<_Float16*>(tail.proj.out2) + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048 + lane * 8;
+#pragma unroll
+              for (int kk = 0; kk < 2; ++kk) {
+                h8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)(ac3[m][n][8 * kk + e] + bv);
+                *reinterpret_cast<h8_t*>(dst + (kk * 2 + mth) * 512) = o;
+              }
+            }
+          } else {
+            f16x_t one[1][2] = {{ac3[m][0], ac3[m][1]}};
+            EpiHeads::template run<1, 2>(tail.proj, one, 0, (int)(t0 >> 5), j, R0, hh);
+          }
+        }
+      } else {
+        EpiF16<false, false>::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
+      }
+    };
+    int vmask = 0;
+    if constexpr (HEADS) {
+#pragma unroll
+      for (int m = 0; m < NEXT_MT; ++m) vmask |= ((((wave * NEXT_MT + m) >> 3) == t_seg) ? 1 : 0) << m;
     }
-    if constexpr (HEADS) EpiHeads::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
-    else EpiF16<false, false>::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
+    vmask = __builtin_amdgcn_readfirstlane(vmask);
+    constexpr int FULL = (1 << NEXT_MT) - 1;
+    if (vmask == 0) run_tail(std::integral_constant<int, 0>{});
+    else if (vmask == FULL) run_tail(std::integral_constant<int, FULL>{});
+    else run_tail(std::integral_constant<int, (FULL & ~1)>{});  // the only mixed pattern: tile 0 is K, the rest V
     if (tail.logsig) {  // matchability head of the last block: one wave per 8 tokens
 #pragma unroll 1
       for (int tk = wave * 8; tk < wave * 8 + 8; ++tk) {
@@ -543,12 +607,17 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
                    float* logsig, hipStream_t s) {
   const int tokens = d.S * d.NP;
   FfnTail t{};
+  static const int dbg = getenv("SSHIP_FFN_DBG") ? atoi(getenv("SSHIP_FFN_DBG")) : 0;
+  t.dbg = dbg;
+  t.copies0 = w0.copies; t.stride0 = w0.copy_stride; t.copies3 = w3.copies; t.stride3 = w3.copy_stride;
+  t.copiesp = 1; t.stridep = 0;
   dim3 grid(tokens / kFfnTok), block(512);
   if (!next) {
     hipLaunchKernelGGL((k_lg_ffn<0, false>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
     return;
   }
   t.proj = token_args(*next, x, 256, nullptr, 0, d);
+  t.copiesp = next->copies; t.stridep = next->copy_stride;
   t.proj.out0 = heads ? (void*)q : (void*)out; t.proj.out1 = k; t.proj.out2 = vt; t.proj.aux = rope;
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
