@@ -174,16 +174,20 @@ hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d,
 //   PV K-step kk uses regs 8kk..8kk+7 = keys {16kk + 4hh + e, 16kk + 8 + 4hh + e}, e = 0..3.
 // Scores arrive pre-scaled by log2(e)/sqrt(64) (folded into the projection weights) -> exp2f.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
-                                                      const _Float16* __restrict__ vt, const int* __restrict__ lens,
-                                                      int NP, int cross, _Float16* __restrict__ ctx) {
-  // One workgroup = 32 queries of one (sequence, head); its 4 waves split the KEYS (tile kt -> wave kt & 3,
-  // flash-decoding style) and merge their (m, l, O) partials through LDS.  4x shorter dependent chains and
-  // 4x more resident waves than one-wave-per-32-queries: the kernel is latency-bound, not MFMA-bound, at N<=1024.
-  __shared__ float s_part[4][34][64];  // [wave][32 O regs + m + l][lane]
+// QT query tiles (32 queries each) per wave share every K / V^T fragment load: the kernel is bound by the L2 -> CU
+// fragment traffic (each workgroup streams the whole K/V of its (sequence, head) once: QT = 1 moved 840 MB per launch
+// at P = 32), so two query tiles per wave halve it at the cost of 2x accumulator registers.
+template <int QT>
+__global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
+                                                         const _Float16* __restrict__ vt, const int* __restrict__ lens,
+                                                         int NP, int cross, _Float16* __restrict__ ctx) {
+  // One workgroup = 32*QT queries of one (sequence, head); its 4 waves split the KEYS (tile kt -> wave kt & 3,
+  // flash-decoding style) and merge their (m, l, O) partials through LDS.
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  float (*s_part)[4][34][64] = reinterpret_cast<float (*)[4][34][64]>(smem_attn);  // [QT][wave][32 O regs + m + l][lane]
   const int s = blockIdx.z, h = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const int q0 = blockIdx.x * 32;
+  const int q0 = blockIdx.x * 32 * QT;
   const int sk = cross ? (s ^ 1) : s;
   const int nq = lens[s], nk = lens[sk];
   if (q0 >= nq) return;  // uniform for the whole workgroup
@@ -193,13 +197,20 @@ __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict
   const _Float16* Q = q + ((size_t)(s * 4 + h) * nt32) * 2048;
   const _Float16* K = k + ((size_t)(sk * 4 + h) * nt32) * 2048;
   const _Float16* VT = vt + ((size_t)(sk * 4 + h) * nt32) * 2048;
-  h8_t qf[4];
+  h8_t qf[QT][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)blockIdx.x * 4 + ks) * 512 + lane * 8);
-  float m = -INFINITY, l = 0.f;
-  f16x_t o[2];
+  for (int t = 0; t < QT; ++t)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    for (int ks = 0; ks < 4; ++ks)
+      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)(blockIdx.x * QT + t) * 4 + ks) * 512 + lane * 8);
+  float m[QT], l[QT];
+  f16x_t o[QT][2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY; l[t] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[t][0][r] = 0.f; o[t][1][r] = 0.f; }
+  }
   const int ntiles = (nk + 31) >> 5;
   // K and V^T fragments are prefetched ONE FULL TILE ahead (loads for tile kt+4 are issued before the MFMAs and
   // softmax of tile kt), so ~1k cycles of L2 latency hide behind a whole iteration instead of a few MFMAs.
@@ -226,42 +237,45 @@ __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict
       for (int mt = 0; mt < 2; ++mt)
         vn[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)ktn * 2 + kk) * 2 + mt) * 512 + lane * 8);
     __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above this tile's MFMAs / softmax
-    f16x_t st;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    for (int t = 0; t < QT; ++t) {
+      f16x_t st;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
-    if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= nk) st[r] = -INFINITY;
-    }
-    float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+      for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
+      if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
 #pragma unroll
-    for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[r], st[r + 1]), fmaxf(st[r + 2], st[r + 3])));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax);
-    // the softmax is VALU-bound at head_dim 64 (profiles/r01_v5_pmc*: 47 VALU per MFMA): rescale the 32 output
-    // accumulators only when some query's running max actually moved (exact - not the lossy defer-max trick)
-    if (__any(m_new > m)) {
-      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-      l *= alpha;
+        for (int r = 0; r < 16; ++r)
+          if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= nk) st[r] = -INFINITY;
+      }
+      float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-      m = m_new;
-    }
-    float ls = 0.f;
-    float p[16];
+      for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[r], st[r + 1]), fmaxf(st[r + 2], st[r + 3])));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m[t], tmax);
+      // the softmax is VALU-bound at head_dim 64: rescale the 32 output accumulators only when some query's running
+      // max actually moved (exact - not the lossy defer-max trick)
+      if (__any(m_new > m[t])) {
+        const float alpha = __builtin_amdgcn_exp2f(m[t] - m_new);
+        l[t] *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(st[r] - m); ls += p[r]; }
-    l += ls;
+        for (int r = 0; r < 16; ++r) { o[t][0][r] *= alpha; o[t][1][r] *= alpha; }
+        m[t] = m_new;
+      }
+      float ls = 0.f;
+      float pr[16];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      h8_t pb;
+      for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(st[r] - m[t]); ls += pr[r]; }
+      l[t] += ls;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pb[e] = (_Float16)p[8 * kk + e];
+      for (int kk = 0; kk < 2; ++kk) {
+        h8_t pb;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) o[mt] = mfma32(vf[kk][mt], pb, o[mt]);
+        for (int e = 0; e < 8; ++e) pb[e] = (_Float16)pr[8 * kk + e];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) o[t][mt] = mfma32(vf[kk][mt], pb, o[t][mt]);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = kn[ks];
@@ -270,45 +284,66 @@ __global__ __launch_bounds__(256) void k_lg_attention(const _Float16* __restrict
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) vf[kk][mt] = vn[kk][mt];
   }
-  l += __shfl_xor(l, 32, 64);
   // ---- merge the 4 key-partials ----
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { s_part[wave][r][lane] = o[0][r]; s_part[wave][16 + r][lane] = o[1][r]; }
-  s_part[wave][32][lane] = m;
-  s_part[wave][33][lane] = l;
+  for (int t = 0; t < QT; ++t) {
+    l[t] += __shfl_xor(l[t], 32, 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s_part[t][wave][r][lane] = o[t][0][r]; s_part[t][wave][16 + r][lane] = o[t][1][r]; }
+    s_part[t][wave][32][lane] = m[t];
+    s_part[t][wave][33][lane] = l[t];
+  }
   __syncthreads();
-  float mw[4], mt_all = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) { mw[w] = s_part[w][32][lane]; mt_all = fmaxf(mt_all, mw[w]); }
-  float sc[4], lt = 0.f;
+  for (int t = 0; t < QT; ++t) {
+    if (q0 + t * 32 >= nq) break;
+    float mw[4], mt_all = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    sc[w] = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - mt_all);
-    lt += s_part[w][33][lane] * sc[w];
-  }
-  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
-  _Float16* orow = ctx + ((size_t)s * NP + q0 + j) * 256 + h * 64;
-  // wave w finalises combined registers R = 8w .. 8w+7 (R = mt*16 + r): two groups of 4 consecutive channels
+    for (int w = 0; w < 4; ++w) { mw[w] = s_part[t][w][32][lane]; mt_all = fmaxf(mt_all, mw[w]); }
+    float sc[4], lt = 0.f;
 #pragma unroll
-  for (int gq = 0; gq < 2; ++gq) {
-    const int R0 = wave * 8 + gq * 4;
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float acc = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) acc += s_part[w][R0 + e][lane] * sc[w];
-      v[e] = acc * inv;
+    for (int w = 0; w < 4; ++w) {
+      sc[w] = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - mt_all);
+      lt += s_part[t][w][33][lane] * sc[w];
     }
-    const int mt = R0 >> 4, r = R0 & 15;
-    const int d = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    *reinterpret_cast<h4_t*>(orow + d) = to_h4(v[0], v[1], v[2], v[3]);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    _Float16* orow = ctx + ((size_t)s * NP + q0 + t * 32 + j) * 256 + h * 64;
+    // wave w finalises combined registers R = 8w .. 8w+7 (R = mt*16 + r): two groups of 4 consecutive channels
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const int R0 = wave * 8 + gq * 4;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += s_part[t][w][R0 + e][lane] * sc[w];
+        v[e] = acc * inv;
+      }
+      const int mt = R0 >> 4, r = R0 & 15;
+      const int d = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      *reinterpret_cast<h4_t*>(orow + d) = to_h4(v[0], v[1], v[2], v[3]);
+    }
   }
+}
+template <int QT>
+static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
+                        _Float16* ctx, hipStream_t s) {
+  constexpr size_t smem = (size_t)QT * 4 * 34 * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_lg_attention<QT>), dim3(d.NP / (32 * QT), 4, d.S), dim3(256), smem, s, q, k, vt, lens, d.NP, cross ? 1 : 0,
+                     ctx);
 }
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                          _Float16* ctx, hipStream_t s) {
-  hipLaunchKernelGGL(k_lg_attention, dim3(d.NP / 32, 4, d.S), dim3(256), 0, s, q, k, vt, lens, d.NP, cross ? 1 : 0,
-                     ctx);
+  // throughput batches: two query tiles per wave (half the K/V fragment traffic); a few pairs only: one tile per wave
+  // so the launch still has enough workgroups to cover the CUs (latency mode)
+  if (d.S * (d.NP / 64) * 4 >= 512) launch_attn<2>(q, k, vt, lens, d, cross, ctx, s);
+  else launch_attn<1>(q, k, vt, lens, d, cross, ctx, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
