@@ -215,7 +215,7 @@ def main():
             except Exception:
                 traffic = None
         alg_bytes = 2 * P * (H * W + (H // 2) * (W // 2) * 64 * 2)   # u8 image in, pooled fp16 64-ch map out
-        roofline = {"kernel": "conv3x3_strip<64,64,pool,fuse1a> (conv1a+conv1b+maxpool, 36 % of the pair's FLOPs)", "bound": "mfma",
+        roofline = {"kernel": "conv3x3_pp<64,64,pool,fuse1a> (conv1a+conv1b+maxpool, 36 % of the pair's FLOPs)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launch_ms": round(ms.value, 4), "flops_per_launch": 2.0 * macs.value,
