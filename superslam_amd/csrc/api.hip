@@ -453,7 +453,8 @@ struct sship_sp {
   hipStream_t stream = nullptr;
   float* w1a = nullptr;  // [9][64] tap-major fp32 (fp16-rounded values)  (stand-alone conv1a kernel)
   float* b1a = nullptr;
-  _Float16* w1a_frag = nullptr;  // conv1a as MFMA A fragments [2][64][8] (K = 9 taps zero-padded to 16)
+  _Float16* w1a_frag = nullptr;   // conv1a as MFMA A fragments [2][64][8] (K = 9 taps zero-padded to 16)
+  _Float16* w1a_fragb = nullptr;  // same + the bias split into fp16 hi/lo parts in K slots 9 and 10 (ping-pong kernel)
   ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, cPa, cPb, cDa, cDb;
   ConvW cDb32;  // convDb packed in 32-row blocks (one per wave of k_desc_head_gather)
   sship_pool* pool = nullptr;
@@ -570,7 +571,7 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
 }
 
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s) {
-  return conv_mode() != 2 ? sp_conv1ab_pp(sp->c1b, sp->w1a_frag, sp->b1a, img, out, B, H, W, s)
+  return conv_mode() != 2 ? sp_conv1ab_pp(sp->c1b, sp->w1a_fragb, sp->b1a, img, out, B, H, W, s)
                           : sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, img, out, B, H, W, s);
 }
 
@@ -620,6 +621,15 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
         }
     SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp->w1a_frag), fr.size() * sizeof(_Float16)));
     SSHIP_HIP_CHECK(hipMemcpy(sp->w1a_frag, fr.data(), fr.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    for (int mt = 0; mt < 2; ++mt)
+      for (int lane = 32; lane < 64; ++lane) {  // hh = 1 lanes hold k = 8 .. 15: e = 1 -> k = 9 (hi), e = 2 -> k = 10 (lo)
+        const int co = mt * 32 + (lane & 31);
+        const _Float16 hi = (_Float16)b->data[co];
+        fr[(mt * 64 + lane) * 8 + 1] = hi;
+        fr[(mt * 64 + lane) * 8 + 2] = (_Float16)(b->data[co] - (float)hi);
+      }
+    SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp->w1a_fragb), fr.size() * sizeof(_Float16)));
+    SSHIP_HIP_CHECK(hipMemcpy(sp->w1a_fragb, fr.data(), fr.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   }
   SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
   if (int rc = sship_pool_create(sp->cfg.pool_slots, sp->cfg.max_keypoints, SSHIP_DESC_DIM, &sp->pool)) return rc;
@@ -634,6 +644,7 @@ extern "C" void sship_sp_destroy(sship_sp* sp) {
   if (sp->w1a) (void)hipFree(sp->w1a);
   if (sp->b1a) (void)hipFree(sp->b1a);
   if (sp->w1a_frag) (void)hipFree(sp->w1a_frag);
+  if (sp->w1a_fragb) (void)hipFree(sp->w1a_fragb);
   if (sp->pool) sship_pool_destroy(sp->pool);
   if (sp->stream) (void)hipStreamDestroy(sp->stream);
   delete sp;

@@ -141,21 +141,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   // q = 32 nt + j and needs taps 8 hh .. 8 hh + 7 of its 3x3 patch (taps 9..15 are the zero padding of K).
   constexpr int NT_W = 3;
   unsigned rp[FUSE1A ? NT_W : 1][3];  // per N-tile: the pixel's 3x3 patch as 3 dwords (bytes 0..2 of patch row r)
+  // tile-invariant geometry of this lane's (up to) 3 halo pixels: q = 32 (gw + 4k) + j -> (py, px), its LDS base and
+  // the swizzle term; computed once per launch (two VGPRs per N-tile)
+  int c1_pypx[FUSE1A ? NT_W : 1], c1_lds[FUSE1A ? NT_W : 1];
+  if constexpr (FUSE1A) {
+#pragma unroll
+    for (int k = 0; k < NT_W; ++k) {
+      const int q = min((gw + 4 * k) * 32 + j, P_THH * P_TWH - 1);
+      const int py = q / P_TWH, px = q - py * P_TWH;
+      c1_pypx[k] = (py << 16) | px;
+      c1_lds[k] = ((py * P_TWH + px) * 64 + hh * 4) | (((px >> 1) & 7) << 24);  // half offset | swizzle term
+    }
+  }
   auto prefetch_u8 = [&](int item) {
     if constexpr (FUSE1A) {
       int b, y0, x0;
       tile_coords(tile_of(item), b, y0, x0);
       const uint8_t* im = p.img + (size_t)b * p.H * p.W;
-      int jv = j;
-      asm volatile("" : "+v"(jv));
       // interior: the whole 12 x 36 patch (+3 bytes of dword over-read) lies inside the image -> three unaligned
       // dword loads per pixel, no clamping (24 clamped byte loads per lane made this the longest part of the step)
       const bool interior = y0 >= 2 && y0 + P_TH + 2 <= p.H && x0 >= 2 && x0 + P_TW + 2 + 3 <= p.W;
 #pragma unroll
       for (int k = 0; k < NT_W; ++k) {
-        const int nt = gw + 4 * k;
-        const int q = min(nt * 32 + jv, P_THH * P_TWH - 1);
-        const int py = q / P_TWH, px = q - py * P_TWH;
+        const int py = c1_pypx[k] >> 16, px = c1_pypx[k] & 0xffff;
         if (interior) {
           const uint8_t* pp = im + (size_t)(y0 - 2 + py) * p.W + (x0 - 2 + px);
 #pragma unroll
@@ -182,12 +190,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       }
     }
   };
+  // conv1a A fragments; the bias rides in two of the K-padding slots (taps 9 and 10 carry fp16 hi / lo parts of the
+  // fp32 bias, the matching B elements are 1.0), so the accumulator comes out of the MFMA already biased.
+  h8_t a1a0, a1a1;
+  if constexpr (FUSE1A) {
+    a1a0 = *reinterpret_cast<const h8_t*>(p.w1a + lane * 8);
+    a1a1 = *reinterpret_cast<const h8_t*>(p.w1a + 512 + lane * 8);
+  }
   auto stage_conv1a = [&](int item) {
     if constexpr (FUSE1A) {
       int b, y0, x0;
       tile_coords(tile_of(item), b, y0, x0);
-      const h8_t a0 = *reinterpret_cast<const h8_t*>(p.w1a + lane * 8);
-      const h8_t a1 = *reinterpret_cast<const h8_t*>(p.w1a + 512 + lane * 8);
+      const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
 #pragma unroll
       for (int k = 0; k < NT_W; ++k) {
         const int nt = gw + 4 * k;
@@ -198,10 +212,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c) t[r][c] = (_Float16)((float)((rp[k][r] >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
-        h8_t bf;  // lanes hh = 0: taps 0..7; lanes hh = 1: tap 8 and the zero padding of K = 9 -> 16
+        h8_t bf;  // lanes hh = 0: taps 0..7; lanes hh = 1: tap 8, the two bias slots (1.0, 1.0) and zero padding
         bf[0] = hh ? t[2][2] : t[0][0];
-        bf[1] = hh ? (_Float16)0.f : t[0][1];
-        bf[2] = hh ? (_Float16)0.f : t[0][2];
+        bf[1] = hh ? (_Float16)1.f : t[0][1];
+        bf[2] = hh ? (_Float16)1.f : t[0][2];
         bf[3] = hh ? (_Float16)0.f : t[1][0];
         bf[4] = hh ? (_Float16)0.f : t[1][1];
         bf[5] = hh ? (_Float16)0.f : t[1][2];
@@ -210,25 +224,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         f16x_t d0, d1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-        d0 = mfma32(a0, bf, d0);
-        d1 = mfma32(a1, bf, d1);
-        const int q = nt * 32 + j;
-        const int py = q / P_TWH, px = q - py * P_TWH;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;  // conv1b's zero padding is on conv1a's OUTPUT
-        if (q < P_THH * P_TWH) {
+        d0 = mfma32(a1a0, bf, d0);
+        d1 = mfma32(a1a1, bf, d1);
+        if ((gw + 4 * k) * 32 + j < P_THH * P_TWH) {
+          bool inside = true;
+          if (!interior) {  // conv1b's zero padding is on conv1a's OUTPUT: only edge tiles have outside halo pixels
+            const int gy = y0 - 1 + (c1_pypx[k] >> 16), gx = x0 - 1 + (c1_pypx[k] & 0xffff);
+            inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          }
+          const int base = c1_lds[k] & 0xffffff, sw = c1_lds[k] >> 24;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int c = hh * 4 + g * 8;  // channels c..c+3 (M-tile 0) and 32 + c .. (M-tile 1): 8-byte half units
-            const float4 b0v = *reinterpret_cast<const float4*>(s_bias + 64 + c);
-            const float4 b1v = *reinterpret_cast<const float4*>(s_bias + 64 + 32 + c);
-            h4_t o0 = to_h4(fmaxf(d0[4 * g] + b0v.x, 0.f), fmaxf(d0[4 * g + 1] + b0v.y, 0.f), fmaxf(d0[4 * g + 2] + b0v.z, 0.f),
-                            fmaxf(d0[4 * g + 3] + b0v.w, 0.f));
-            h4_t o1 = to_h4(fmaxf(d1[4 * g] + b1v.x, 0.f), fmaxf(d1[4 * g + 1] + b1v.y, 0.f), fmaxf(d1[4 * g + 2] + b1v.z, 0.f),
-                            fmaxf(d1[4 * g + 3] + b1v.w, 0.f));
+            h4_t o0 = to_h4(fmaxf(d0[4 * g], 0.f), fmaxf(d0[4 * g + 1], 0.f), fmaxf(d0[4 * g + 2], 0.f), fmaxf(d0[4 * g + 3], 0.f));
+            h4_t o1 = to_h4(fmaxf(d1[4 * g], 0.f), fmaxf(d1[4 * g + 1], 0.f), fmaxf(d1[4 * g + 2], 0.f), fmaxf(d1[4 * g + 3], 0.f));
             if (!inside) { o0 = to_h4(0.f, 0.f, 0.f, 0.f); o1 = o0; }
-            *reinterpret_cast<h4_t*>(my_in + pp_lds(py, px, c >> 3) + (c & 7)) = o0;
-            *reinterpret_cast<h4_t*>(my_in + pp_lds(py, px, (32 + c) >> 3) + (c & 7)) = o1;
+            const int u0 = (g ^ sw) << 3;  // channels 4 hh + 8 g .. (+3): unit g; M-tile 1: unit 4 + g
+            *reinterpret_cast<h4_t*>(my_in + base + u0) = o0;
+            *reinterpret_cast<h4_t*>(my_in + base + (u0 ^ 32)) = o1;
           }
         }
       }
