@@ -631,7 +631,9 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
     SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp->w1a_fragb), fr.size() * sizeof(_Float16)));
     SSHIP_HIP_CHECK(hipMemcpy(sp->w1a_fragb, fr.data(), fr.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   }
-  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
+  // blocking stream: ordered with the legacy default stream, so a caller that passes stream = NULL (e.g. torch's default
+  // stream, whose handle IS 0) still gets its work ordered against ours
+  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&sp->stream, hipStreamDefault));
   if (int rc = sship_pool_create(sp->cfg.pool_slots, sp->cfg.max_keypoints, SSHIP_DESC_DIM, &sp->pool)) return rc;
   *out = sp.release();
   return SSHIP_OK;
@@ -1028,7 +1030,7 @@ extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, in
   SSHIP_HIP_CHECK(hipMemset(lg->k.p, 0, lg->k.bytes));
   SSHIP_HIP_CHECK(hipMemset(lg->vt.p, 0, lg->vt.bytes));
   SSHIP_HIP_CHECK(hipMemset(lg->ctx.p, 0, lg->ctx.bytes));
-  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&lg->stream, hipStreamNonBlocking));
+  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&lg->stream, hipStreamDefault));
   sship_lg_weights_retain(w);
   lg->w = w;
   *out = lg.release();

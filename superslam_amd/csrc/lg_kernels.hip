@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_lg_prep(const float* __restrict__ kp, i
   const int lane = threadIdx.x & 63;
   if (token >= S * NP) return;
   const int s = token / NP, n = token % NP;
-  const bool valid = n < lens[s];
+  const bool valid = n < min(max(lens[s], 0), NP);
   h4_t v = to_h4(0.f, 0.f, 0.f, 0.f);
   if (valid) v = *reinterpret_cast<const h4_t*>(desc + (size_t)s * desc_seq_stride + (size_t)n * 256 + lane * 4);
   *reinterpret_cast<h4_t*>(x + (size_t)token * 256 + lane * 4) = v;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
   const int q0 = blockIdx.x * 32 * QT;
   const int sk = cross ? (s ^ 1) : s;
-  const int nq = lens[s], nk = lens[sk];
+  const int nq = min(max(lens[s], 0), NP), nk = min(max(lens[sk], 0), NP);  // device-side counts are clamped to capacity
   if (q0 >= nq) return;  // uniform for the whole workgroup
   // Q/K/V are stored in MFMA-fragment order per 32-token tile (EpiHeads): every operand load below is one
   // fully coalesced 1-KiB wave load (16 B per lane, lane-linear).
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void k_lg_sim(const _Float16* __restrict__ md,
   const int pair = blockIdx.z;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jl = lane & 31, hh = lane >> 5;
   const int i0 = blockIdx.y * 32, j0 = (blockIdx.x * 4 + wave) * 32;
-  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   if (i0 >= n0 || j0 >= n1) return;
   const _Float16* A = md + ((size_t)(2 * pair) * NP + i0 + jl) * 256 + hh * 8;
   const _Float16* Bm = md + ((size_t)(2 * pair + 1) * NP + j0 + jl) * 256 + hh * 8;
@@ -712,7 +712,7 @@ void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hi
 __global__ __launch_bounds__(256) void k_assign_row_lse(const float* __restrict__ sim, const int* __restrict__ lens,
                                                         int NP, float* __restrict__ ws) {
   const int pair = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   if (i >= n0) return;
   const float* row = sim + ((size_t)pair * NP + i) * NP;
   float m = -INFINITY;
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void k_assign_col_lse(const float* __restrict_
   __shared__ float s_m[4][64], s_s[4][64];
   const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + cl;
-  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   float m = -INFINITY, sum = 0.f;
   if (j < n1) {
     const float* col = sim + (size_t)pair * NP * NP + j;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void k_assign_col_lse(const float* __restrict_
 __global__ __launch_bounds__(256) void k_assign_row_arg(const float* __restrict__ sim, const float* __restrict__ logsig,
                                                         const int* __restrict__ lens, int NP, float* __restrict__ ws) {
   const int pair = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   if (i >= n0) return;
   float* w = ws + (size_t)pair * 5 * NP;
   const float* row = sim + ((size_t)pair * NP + i) * NP;
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void k_assign_col_arg(const float* __restrict_
   __shared__ int s_i[4][64];
   const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + cl;
-  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   float* w = ws + (size_t)pair * 5 * NP;
   float best = -INFINITY;
   int bi = 0x7fffffff;
@@ -806,7 +806,7 @@ __global__ void k_assign_final(const int* __restrict__ lens, int NP, const float
                                float thr, int32_t* __restrict__ matches0, float* __restrict__ mscores0) {
   const int pair = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= max_kp) return;
-  const int n0 = lens[2 * pair], n1 = lens[2 * pair + 1];
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   const float* w = ws + (size_t)pair * 5 * NP;
   int mj = -1;
   float ms = 0.f;

@@ -423,3 +423,54 @@ def test_offline_extraction_sharded_equals_direct(sp, hip):
         nn = int(full_n[i])
         assert torch.equal(torch.cat([p[1] for p in parts])[i, :nn], full_k[i, :nn])
         assert torch.equal(torch.cat([p[0] for p in parts])[i, :nn], full_d[i, :nn])
+
+
+def test_engine_max_keypoints_1024_and_odd_kitti_width(hip, weights_dir):
+    """The reference engine's upper profile: 1024 keypoints (scripts/rebuild_engines.sh:118) on the real KITTI size
+    1241x376 (odd width: grid 155, score map 1240 wide, keypoint x rescaled by 1241/1240 - src/SuperPoint.cc:707-708)."""
+    from superslam_amd import LightGlue, SuperPoint
+    from superslam_amd.synth import make_stereo_pair
+
+    sp = SuperPoint(weights_dir["sp_path"], 1024, 0.005, 4)
+    lg = LightGlue(weights_dir["lg_path"], 1241, 376, max_keypoints=1024)
+    assert sp.initialize() and lg.initialize()
+    l, r = make_stereo_pair(376, 1241, 99)
+    fl, fr = sp.extract_stereo(l, r)
+    assert len(fl.keypoints) == 1024 and len(fr.keypoints) == 1024
+    x = R.preprocess_u8(torch.from_numpy(np.stack([l, r])))
+    with torch.no_grad():
+        s, _ = R.dense_forward(weights_dir["sp"], x, emulate_fp16=True)
+    assert s.shape[1:] == (376, 1240)
+    ref = H.select_topk(s[0].numpy(), 376, 1241, 0.005, 4, 1024, 47, 155)
+    a = {(round(float(k[0]), 2), int(k[1])) for k in fl.keypoints}
+    b = {(round(float(k[0]), 2), int(k[1])) for k in ref["kp"]}
+    iou = len(a & b) / len(a | b)
+    print(f"1241x376 / 1024 kp: keypoint IoU vs oracle {iou:.4f}, max x {fl.keypoints[:, 0].max():.2f}")
+    assert iou > 0.9
+    assert np.allclose(fl.keypoints[:, 0] / np.float32(1241 / 1240), np.round(fl.keypoints[:, 0] / np.float32(1241 / 1240)), atol=1e-3)
+    res = lg.match(fl.keypoints, fl.descriptors, fr.keypoints, fr.descriptors)
+    d0, d1 = lg.descriptors_to_host(fl.descriptors), lg.descriptors_to_host(fr.descriptors)
+    k0, k1 = H.normalize_kpts(fl.keypoints, 1241, 376), H.normalize_kpts(fr.keypoints, 1241, 376)
+    with torch.no_grad():
+        m_ref, s_ref = LR.match(weights_dir["lg"], torch.from_numpy(k0)[None], torch.from_numpy(d0)[None],
+                                torch.from_numpy(k1)[None], torch.from_numpy(d1)[None], dtype=torch.float32)
+    agree = (res.matches0 == m_ref[0].numpy()).mean()
+    ds = np.abs(res.mscores0 - s_ref[0].numpy()).max()
+    print(f"N=1024 LG: matched {int((res.matches0 >= 0).sum())}, agreement {agree:.4f}, mscores max|d| {ds:.3e}")
+    assert agree >= 0.99 and ds <= 2e-2
+    sp.close(); lg.close()
+
+
+def test_lightglue_ragged_sets(lg):
+    """n0 != n1, n not a multiple of 32, tiny sets: shapes and -1 padding behave (reference filters -1 on the host)."""
+    rng = np.random.default_rng(21)
+    for n0, n1 in ((1, 1), (33, 5), (599, 600), (600, 17)):
+        kp0 = np.stack([rng.uniform(0, 1376, n0), rng.uniform(0, 376, n0)], 1).astype(np.float32)
+        kp1 = np.stack([rng.uniform(0, 1376, n1), rng.uniform(0, 376, n1)], 1).astype(np.float32)
+        d0 = rng.standard_normal((n0, 256)).astype(np.float32); d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+        d1 = rng.standard_normal((n1, 256)).astype(np.float32); d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+        res = lg.match(kp0, d0, kp1, d1)
+        assert res.matches0.shape == (n0,) and res.mscores0.shape == (n0,)
+        assert ((res.matches0 >= -1) & (res.matches0 < n1)).all()
+        assert np.isfinite(res.mscores0).all() and (res.mscores0 >= 0).all() and (res.mscores0 <= 1.0 + 1e-5).all()
+        assert len(set(res.train_idx.tolist())) == len(res.train_idx)   # mutual matches are one-to-one
