@@ -198,8 +198,10 @@ def main():
         _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, 1, 2 * P, H, W, 20, C.byref(ms), C.byref(macs)))
         ach = 2.0 * macs.value / (ms.value * 1e-3) / 1e12
         layer_ms = {}
-        for lid, name in enumerate(["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b",
-                                    "convPa", "convPb", "convDa", "convDb"]):
+        # layer 0 / 11 are stand-alone reference kernels that are NOT on the extraction path (conv1a is fused into
+        # conv1b's staging, convDb runs only at the selected keypoints inside k_desc_head_gather)
+        for lid, name in enumerate(["conv1a_standalone_offpath", "conv1a+conv1b+pool", "conv2a", "conv2b+pool", "conv3a",
+                                    "conv3b+pool", "conv4a", "conv4b", "convPa", "convPb", "convDa", "convDb_dense_offpath"]):
             m2 = C.c_float(0)
             _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, lid, 2 * P, H, W, 10, C.byref(m2), None))
             layer_ms[name] = round(m2.value, 4)

@@ -836,7 +836,6 @@ struct sship_lg_weights {
   ConvW qkv_t[kLgLayers], cqkv_t[kLgLayers], final_t;            // same projections packed per wave for the FFN tail
   ConvW cqkv[kLgLayers], ffn0_c[kLgLayers], ffn3_c[kLgLayers];
   float *ln_g_s[kLgLayers] = {}, *ln_b_s[kLgLayers] = {}, *ln_g_c[kLgLayers] = {}, *ln_b_c[kLgLayers] = {};
-  ConvW final_proj;
   float* match_w = nullptr;
   float match_b = 0.f;
   float* wr = nullptr;
@@ -847,7 +846,6 @@ static void lg_weights_free(sship_lg_weights* w) {
       free_conv(*c);
     for (float* p : {w->ln_g_s[i], w->ln_b_s[i], w->ln_g_c[i], w->ln_b_c[i]}) if (p) (void)hipFree(p);
   }
-  free_conv(w->final_proj);
   free_conv(w->final_t);
   if (w->match_w) (void)hipFree(w->match_w);
   if (w->wr) (void)hipFree(w->wr);
@@ -957,7 +955,6 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     // depth_confidence = -1 -> only log_assignment[n_layers - 1] is evaluated (convert_lightglue_to_onnx.py:71-74)
     const std::string pa = "log_assignment." + std::to_string(kLgLayers - 1) + ".";
     int rc = 0;
-    if ((rc = lin(pa + "final_proj", 256, 256, w->final_proj, nullptr, &fp_scale))) return bail(rc, err);
     {
       const Tensor* wt = find_tensor(sd, pa + "final_proj.weight", {256, 256}, err);
       const Tensor* bs = find_tensor(sd, pa + "final_proj.bias", {256}, err);

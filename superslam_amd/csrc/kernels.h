@@ -61,8 +61,6 @@ struct ConvW {          // one packed conv / linear layer on the device
   size_t copy_stride = 0;  // halfs between replicas
 };
 // in: channels-last fp16 [B,H,W,cin]; out: [B,Ho,Wo,cout] fp16 (pool: floor(/2)).
-hipError_t sp_conv3x3(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, bool relu,
-                      hipStream_t s);
 hipError_t sp_conv3x3_strip(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool,
                             hipStream_t s);
 hipError_t sp_conv1ab_fused(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img,
@@ -86,16 +84,12 @@ void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int
                     float* rope, hipStream_t s);
 hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope_segs, int t_seg,
                            const float* rope, _Float16* q, _Float16* k, _Float16* vt, hipStream_t s);
-hipError_t lg_linear_f16(const ConvW& w, const _Float16* in0, int cs0, const _Float16* in1, int cs1, LgDims d,
-                         _Float16* out, int ostride, hipStream_t s);
-hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d, _Float16* x, hipStream_t s);
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,
                          bool cross, _Float16* ctx, hipStream_t s);
 void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
                    _Float16* x, LgDims d, const ConvW* next, bool heads, int rope_segs, int t_seg, const float* rope,
                    _Float16* q, _Float16* k, _Float16* vt, _Float16* out, const float* match_w, float match_b,
                    float* logsig, hipStream_t s);
-void launch_lg_matchability(const _Float16* x, const float* w, float bias, int tokens, float* logsig, hipStream_t s);
 void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s);
 void launch_lg_assign(const float* sim, const float* logsig, const int* lens, LgDims d, float* ws, int max_kp,
                       int32_t* matches0, float* mscores0, float thr, hipStream_t s);

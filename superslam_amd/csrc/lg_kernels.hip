@@ -106,32 +106,6 @@ struct EpiHeads {
   }
 };
 
-// x[token] += W h + b   (in place on the fp16 residual stream; the add runs in fp32)
-struct EpiResid {
-  template <int MT, int NT>
-  static __device__ __forceinline__ void run(const IgemmArgs& p, f16x_t (&acc)[MT][NT], int b, int yb, int x,
-                                             int cb0, int hh) {
-    _Float16* xs = static_cast<_Float16*>(p.out0);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      if (yb + n >= p.H) continue;
-      const size_t token = (size_t)(yb + n) * 32 + x;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = cb0 + m * 32 + hh * 4 + g * 8;
-          if (c >= p.cout) continue;
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + c);
-          h4_t* px = reinterpret_cast<h4_t*>(xs + token * p.ostride + c);
-          const h4_t o = *px;
-          *px = to_h4((float)o[0] + (acc[m][n][4 * g + 0] + bv.x), (float)o[1] + (acc[m][n][4 * g + 1] + bv.y),
-                      (float)o[2] + (acc[m][n][4 * g + 2] + bv.z), (float)o[3] + (acc[m][n][4 * g + 3] + bv.w));
-        }
-    }
-  }
-};
-
 static IgemmArgs token_args(const ConvW& w, const _Float16* in0, int cs0, const _Float16* in1, int cs1, LgDims d) {
   IgemmArgs a{};
   a.in0 = in0; a.in1 = in1 ? in1 : in0; a.cs0 = cs0; a.cs1 = in1 ? cs1 : cs0;
@@ -148,22 +122,6 @@ hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope
   a.out0 = q; a.out1 = k; a.out2 = vt; a.aux = rope; a.flags = rope_segs | (t_seg << 4);
   return launch_igemm<1, 256, 128, 4, EpiHeads>(a, w.cout_pad, s);
 }
-hipError_t lg_linear_f16(const ConvW& w, const _Float16* in0, int cs0, const _Float16* in1, int cs1, LgDims d,
-                         _Float16* out, int ostride, hipStream_t s) {
-  IgemmArgs a = token_args(w, in0, cs0, in1, cs1, d);
-  a.out0 = out; a.ostride = ostride;
-  if (w.cin == 256) {
-    if (w.ct == 64) return launch_igemm<1, 256, 64, 4, EpiF16<false, false>>(a, w.cout_pad, s);
-    return launch_igemm<1, 256, 128, 4, EpiF16<false, false>>(a, w.cout_pad, s);
-  }
-  return launch_igemm<1, 512, 128, 4, EpiF16<false, false>>(a, w.cout_pad, s);
-}
-hipError_t lg_linear_resid(const ConvW& w, const _Float16* in, int cs, LgDims d, _Float16* x, hipStream_t s) {
-  IgemmArgs a = token_args(w, in, cs, nullptr, 0, d);
-  a.out0 = x; a.ostride = 256;
-  return launch_igemm<1, 512, 64, 4, EpiResid>(a, w.cout_pad, s);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Flash-style attention, one wave per 32 queries, head_dim 64.  Self (keys = own sequence) and cross
 // (keys = partner sequence s^1: both directions of CrossBlock in one launch).
@@ -660,23 +618,6 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   if (heads && mt == 3) hipLaunchKernelGGL((k_lg_ffn<3, true>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
   else if (heads && mt == 2) hipLaunchKernelGGL((k_lg_ffn<2, true>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
   else hipLaunchKernelGGL((k_lg_ffn<1, false>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
-}
-
-// logsigmoid(matchability(x)) per token.
-__global__ __launch_bounds__(256) void k_lg_matchability(const _Float16* __restrict__ x, const float* __restrict__ w,
-                                                         float bias, int tokens, float* __restrict__ logsig) {
-  const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (token >= tokens) return;
-  const h4_t v = *reinterpret_cast<const h4_t*>(x + (size_t)token * 256 + lane * 4);
-  float d = 0.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) d += (float)v[e] * w[lane * 4 + e];
-  const float z = wave_sum(d) + bias;
-  if (lane == 0) logsig[token] = fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
-}
-void launch_lg_matchability(const _Float16* x, const float* w, float bias, int tokens, float* logsig, hipStream_t s) {
-  hipLaunchKernelGGL(k_lg_matchability, dim3((tokens + 3) / 4), dim3(256), 0, s, x, w, bias, tokens, logsig);
 }
 
 // ---------------------------------------------------------------------------------------------------
