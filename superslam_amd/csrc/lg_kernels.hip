@@ -331,76 +331,87 @@ struct FfnTail {
   float match_b;
   float* logsig;           // ... -> logsigmoid(z) per token
 };
-template <int NEXT_MT, bool HEADS>
-__global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
+// NW = waves per workgroup.  8: one 512-thread workgroup per CU (the kernel needs > 128 VGPRs), every wave owns one
+// row block per GEMM.  4: two independent 256-thread workgroups per CU, every wave owns RB = 2 row blocks and runs them
+// back to back on the same LDS token tile - the staging / LayerNorm barriers / epilogue stores of one workgroup
+// overlap the MFMA phases of the other instead of idling the CU.  Same packed weights, same arithmetic order.
+template <int NEXT_MT, bool HEADS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                 const float* __restrict__ b0, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
                                                 const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
+  constexpr int RB = 8 / NW, NTHR = NW * 64;
+  constexpr int G0 = 8 / RB;    // ffn.0 k-steps per register-prefetch group
+  constexpr int G3 = 16 / RB;   // ffn.3 k-steps per group
   __shared__ __attribute__((aligned(16))) _Float16 s_x[kFfnTok * kFfnLd];
-  __shared__ float s_red[8][kFfnTok];
+  __shared__ float s_red[NW][kFfnTok];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
   const size_t t0 = (size_t)blockIdx.x * kFfnTok;
-  for (int u = tid; u < kFfnTok * 64; u += 512) {
+  for (int u = tid; u < kFfnTok * 64; u += NTHR) {
     const int tok = u >> 6, part = u & 63;
     const _Float16* src = part < 32 ? x + (t0 + tok) * 256 + part * 8 : ctx + (t0 + tok) * 256 + (part - 32) * 8;
     *reinterpret_cast<uint4*>(s_x + tok * kFfnLd + part * 8) = (tail.dbg & 16) ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(src);
   }
   __syncthreads();
-  // ---- ffn.0 : rows [64 wave, +64) x 64 tokens, K = 512 ----
-  f16x_t acc[2][2];
+  // ---- ffn.0 : row blocks cb = wave*RB + rb, rows [64 cb, +64) x 64 tokens, K = 512 ----
+  f16x_t acc[RB][2][2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  {
-    // Weight fragments stream from L2 (no reuse between waves); keep TWO groups of 8 k-steps (32 KiB per wave) in
-    // flight in registers so ~1k cycles of L2 latency are covered by the 16 MFMAs (512+ cycles) of the previous
-    // group and the co-resident wave.
-    const _Float16* wp = w0p + (blockIdx.x % tail.copies0) * tail.stride0 + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
-    h8_t ab[2][8][2];
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+        for (int r = 0; r < 16; ++r) acc[rb][m][n][r] = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    // Weight fragments stream from L2 (no reuse between waves); keep TWO groups of G0 k-steps in flight in registers
+    // so ~1k cycles of L2 latency are covered by the MFMAs of the previous group and the co-resident waves.
+    const _Float16* wp = w0p + (blockIdx.x % tail.copies0) * tail.stride0 + (size_t)(wave * RB + rb) * (32 * 2 * 512) + lane * 8;  // packed [cb][k16][mt][lane][8]
+    h8_t ab[2][G0][2];
+#pragma unroll
+    for (int i = 0; i < G0; ++i) {
       ab[0][i][0] = *reinterpret_cast<const h8_t*>(wp + (i * 2 + 0) * 512);
       ab[0][i][1] = *reinterpret_cast<const h8_t*>(wp + (i * 2 + 1) * 512);
     }
 #pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
+    for (int grp = 0; grp < 32 / G0; ++grp) {
       if (tail.dbg & 1) break;
-      if (grp + 1 < 4) {
+      if (grp + 1 < 32 / G0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          ab[(grp + 1) & 1][i][0] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * 8 + i) * 2 + 0) * 512);
-          ab[(grp + 1) & 1][i][1] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * 8 + i) * 2 + 1) * 512);
+        for (int i = 0; i < G0; ++i) {
+          ab[(grp + 1) & 1][i][0] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * G0 + i) * 2 + 0) * 512);
+          ab[(grp + 1) & 1][i][1] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * G0 + i) * 2 + 1) * 512);
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads ABOVE this group's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int ks = grp * 8 + i;
+      for (int i = 0; i < G0; ++i) {
+        const int ks = grp * G0 + i;
         const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
         const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
-        acc[0][0] = mfma32(ab[grp & 1][i][0], bf0, acc[0][0]);
-        acc[0][1] = mfma32(ab[grp & 1][i][0], bf1, acc[0][1]);
-        acc[1][0] = mfma32(ab[grp & 1][i][1], bf0, acc[1][0]);
-        acc[1][1] = mfma32(ab[grp & 1][i][1], bf1, acc[1][1]);
+        acc[rb][0][0] = mfma32(ab[grp & 1][i][0], bf0, acc[rb][0][0]);
+        acc[rb][0][1] = mfma32(ab[grp & 1][i][0], bf1, acc[rb][0][1]);
+        acc[rb][1][0] = mfma32(ab[grp & 1][i][1], bf0, acc[rb][1][0]);
+        acc[rb][1][1] = mfma32(ab[grp & 1][i][1], bf1, acc[rb][1][1]);
       }
     }
   }
-  // ---- bias, LayerNorm(512) over the row dimension (spread over regs, lane^32 and the 8 waves), GELU ----
+  // ---- bias, LayerNorm(512) over the row dimension (spread over regs, lane^32 and the waves), GELU ----
   float sum[2] = {0.f, 0.f};
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 bv = *reinterpret_cast<const float4*>(b0 + wave * 64 + m * 32 + hh * 4 + g * 8);
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        acc[m][n][4 * g + 0] += bv.x; acc[m][n][4 * g + 1] += bv.y; acc[m][n][4 * g + 2] += bv.z; acc[m][n][4 * g + 3] += bv.w;
-        sum[n] += (acc[m][n][4 * g + 0] + acc[m][n][4 * g + 1]) + (acc[m][n][4 * g + 2] + acc[m][n][4 * g + 3]);
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(b0 + (wave * RB + rb) * 64 + m * 32 + hh * 4 + g * 8);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          acc[rb][m][n][4 * g + 0] += bv.x; acc[rb][m][n][4 * g + 1] += bv.y; acc[rb][m][n][4 * g + 2] += bv.z; acc[rb][m][n][4 * g + 3] += bv.w;
+          sum[n] += (acc[rb][m][n][4 * g + 0] + acc[rb][m][n][4 * g + 1]) + (acc[rb][m][n][4 * g + 2] + acc[rb][m][n][4 * g + 3]);
+        }
       }
-    }
   float mean[2], rstd[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   for (int n = 0; n < 2; ++n) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
+    for (int w = 0; w < NW; ++w) t += s_red[w][n * 32 + j];
     mean[n] = t * (1.0f / 512.0f);
   }
   __syncthreads();
@@ -420,9 +431,11 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   for (int n = 0; n < 2; ++n) {
     float sq = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float dlt = acc[m][n][r] - mean[n]; sq += dlt * dlt; }
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float dlt = acc[rb][m][n][r] - mean[n]; sq += dlt * dlt; }
     sq += __shfl_xor(sq, 32, 64);
     if (hh == 0) s_red[wave][n * 32 + j] = sq;
   }
@@ -431,96 +444,103 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   for (int n = 0; n < 2; ++n) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
+    for (int w = 0; w < NW; ++w) t += s_red[w][n * 32 + j];
     rstd[n] = rsqrtf(t * (1.0f / 512.0f) + 1e-5f);
   }
   // every wave has passed two barriers since its last read of s_x: the tile can be overwritten with the hidden tile
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = wave * 64 + m * 32 + hh * 4 + g * 8;
-      const float4 gv = *reinterpret_cast<const float4*>(gamma + c);
-      const float4 be = *reinterpret_cast<const float4*>(beta + c);
-      const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        float o[4];
+      for (int g = 0; g < 4; ++g) {
+        const int c = (wave * RB + rb) * 64 + m * 32 + hh * 4 + g * 8;
+        const float4 gv = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float y = (acc[m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
-          o[e] = (tail.dbg & 2) ? y : 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
+        for (int n = 0; n < 2; ++n) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = (acc[rb][m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
+            o[e] = (tail.dbg & 2) ? y : 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
+          }
+          *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
       }
-    }
   __syncthreads();
-  // ---- ffn.3 : rows [32 wave, +32) x 64 tokens, K = 512, + residual ----
-  f16x_t ac2[2];
+  // ---- ffn.3 : row blocks cb = wave*RB + rb, rows [32 cb, +32) x 64 tokens, K = 512, + residual ----
+  f16x_t ac2[RB][2];
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ac2[n][r] = 0.f;
-  {
-    const _Float16* wp = w3p + (blockIdx.x % tail.copies3) * tail.stride3 + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
-    h8_t a3[2][16];
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
+      for (int r = 0; r < 16; ++r) ac2[rb][n][r] = 0.f;
 #pragma unroll
-    for (int grp = 0; grp < 2; ++grp) {
+  for (int rb = 0; rb < RB; ++rb) {
+    const _Float16* wp = w3p + (blockIdx.x % tail.copies3) * tail.stride3 + (size_t)(wave * RB + rb) * (32 * 512) + lane * 8;  // packed [cb][k16][mt = 0][lane][8]
+    h8_t a3[2][G3];
+#pragma unroll
+    for (int i = 0; i < G3; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
+#pragma unroll
+    for (int grp = 0; grp < 32 / G3; ++grp) {
       if (tail.dbg & 4) break;
-      if (grp == 0) {
+      if (grp + 1 < 32 / G3) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a3[1][i] = *reinterpret_cast<const h8_t*>(wp + (16 + i) * 512);
+        for (int i = 0; i < G3; ++i) a3[(grp + 1) & 1][i] = *reinterpret_cast<const h8_t*>(wp + ((grp + 1) * G3 + i) * 512);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ks = grp * 16 + i;
+      for (int i = 0; i < G3; ++i) {
+        const int ks = grp * G3 + i;
         const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
         const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
-        ac2[0] = mfma32(a3[grp][i], bf0, ac2[0]);
-        ac2[1] = mfma32(a3[grp][i], bf1, ac2[1]);
+        ac2[rb][0] = mfma32(a3[grp & 1][i], bf0, ac2[rb][0]);
+        ac2[rb][1] = mfma32(a3[grp & 1][i], bf1, ac2[rb][1]);
       }
     }
   }
   if constexpr (NEXT_MT > 0) __syncthreads();  // all waves are done reading the hidden tile: s_x gets the new x
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int c = wave * 32 + hh * 4 + g * 8;
-    const float4 bv = *reinterpret_cast<const float4*>(b3 + c);
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
-      if (tail.dbg & 64) continue;
-      const h4_t o = *px;
-      const h4_t xn = to_h4((float)o[0] + (ac2[n][4 * g + 0] + bv.x), (float)o[1] + (ac2[n][4 * g + 1] + bv.y),
-                            (float)o[2] + (ac2[n][4 * g + 2] + bv.z), (float)o[3] + (ac2[n][4 * g + 3] + bv.w));
-      *px = xn;
-      if constexpr (NEXT_MT > 0) *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = xn;
+    for (int g = 0; g < 4; ++g) {
+      const int c = (wave * RB + rb) * 32 + hh * 4 + g * 8;
+      const float4 bv = *reinterpret_cast<const float4*>(b3 + c);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
+        if (tail.dbg & 64) continue;
+        const h4_t o = *px;
+        const h4_t xn = to_h4((float)o[0] + (ac2[rb][n][4 * g + 0] + bv.x), (float)o[1] + (ac2[rb][n][4 * g + 1] + bv.y),
+                              (float)o[2] + (ac2[rb][n][4 * g + 2] + bv.z), (float)o[3] + (ac2[rb][n][4 * g + 3] + bv.w));
+        *px = xn;
+        if constexpr (NEXT_MT > 0) *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = xn;
+      }
     }
-  }
   if constexpr (NEXT_MT > 0) {
     __syncthreads();
-    // ---- fused next projection: rows [NEXT_MT*32*wave, +NEXT_MT*32) x 64 tokens, K = 256 ----
-    f16x_t ac3[NEXT_MT][2];
-#pragma unroll
-    for (int m = 0; m < NEXT_MT; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
-    const _Float16* wp = tail.proj.wpack + (blockIdx.x % tail.copiesp) * tail.stridep + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
+    // ---- fused next projection: row blocks cb = wave*RB + rb, rows [NEXT_MT*32*cb, +NEXT_MT*32) x 64 tokens, K = 256 ----
     // M-tiles of the V segment run with SWAPPED operands (A = token tile, B = weights): the accumulator then holds
     // D[token][channel] with lane = channel and 8 consecutive registers = the 8 keys of one PV A-fragment unit, so V^T is
     // written in fragment order with one 16-byte store per lane (the 2-byte transposing stores it replaces were ~16x
     // write-amplified and dominated the kernel's non-MFMA time).
     const int t_seg = (tail.proj.flags >> 4) & 0xf;
-    // which of this wave's M-tiles belong to the V segment is wave-uniform; the loop is instantiated per pattern
-    // (VMASK bit m = tile m is V) so its body stays branch-free: self Wqkv (3 tiles/wave): 000, 110 (wave 5), 111;
-    // cross [to_qk|to_v] (2 tiles/wave): 00, 11.
-    auto run_tail = [&](auto vmask_c) {
+    // which of a row block's M-tiles belong to the V segment is wave-uniform; the loop is instantiated per pattern
+    // (VMASK bit m = tile m is V) so its body stays branch-free: self Wqkv (3 tiles/block): 000, 110 (block 5), 111;
+    // cross [to_qk|to_v] (2 tiles/block): 00, 11.
+    auto run_tail = [&](auto vmask_c, int cb) {
       constexpr int VMASK = decltype(vmask_c)::value;
+      f16x_t ac3[NEXT_MT][2];
+#pragma unroll
+      for (int m = 0; m < NEXT_MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
+      const _Float16* wp = tail.proj.wpack + (blockIdx.x % tail.copiesp) * tail.stridep + (size_t)cb * (16 * NEXT_MT * 512) + lane * 8;  // [cb][k16][mt][lane][8]
 #pragma unroll 16
       for (int ks = 0; ks < 16; ++ks) {
         if (tail.dbg & 8) break;
@@ -543,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         const int NP = tail.proj.np, nt32 = NP >> 5;
 #pragma unroll
         for (int m = 0; m < NEXT_MT; ++m) {
-          const int R0 = (wave * NEXT_MT + m) * 32;  // first output row of this M-tile
+          const int R0 = (cb * NEXT_MT + m) * 32;  // first output row of this M-tile
           if ((VMASK >> m) & 1) {
             const int hd = (R0 >> 6) & 3, mth = (R0 >> 5) & 1;  // head, 32-channel half of the head
             const float bv = tail.proj.bias[R0 + j];
@@ -566,22 +586,26 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
           }
         }
       } else {
-        EpiF16<false, false>::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
+        EpiF16<false, false>::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, cb * NEXT_MT * 32, hh);
       }
     };
-    int vmask = 0;
-    if constexpr (HEADS) {
-#pragma unroll
-      for (int m = 0; m < NEXT_MT; ++m) vmask |= ((((wave * NEXT_MT + m) >> 3) == t_seg) ? 1 : 0) << m;
-    }
-    vmask = __builtin_amdgcn_readfirstlane(vmask);
     constexpr int FULL = (1 << NEXT_MT) - 1;
-    if (vmask == 0) run_tail(std::integral_constant<int, 0>{});
-    else if (vmask == FULL) run_tail(std::integral_constant<int, FULL>{});
-    else run_tail(std::integral_constant<int, (FULL & ~1)>{});  // the only mixed pattern: tile 0 is K, the rest V
-    if (tail.logsig) {  // matchability head of the last block: one wave per 8 tokens
 #pragma unroll 1
-      for (int tk = wave * 8; tk < wave * 8 + 8; ++tk) {
+    for (int rb = 0; rb < RB; ++rb) {
+      const int cb = wave * RB + rb;
+      int vmask = 0;
+      if constexpr (HEADS) {
+#pragma unroll
+        for (int m = 0; m < NEXT_MT; ++m) vmask |= ((((cb * NEXT_MT + m) >> 3) == t_seg) ? 1 : 0) << m;
+      }
+      vmask = __builtin_amdgcn_readfirstlane(vmask);
+      if (vmask == 0) run_tail(std::integral_constant<int, 0>{}, cb);
+      else if (vmask == FULL) run_tail(std::integral_constant<int, FULL>{}, cb);
+      else run_tail(std::integral_constant<int, (FULL & ~1)>{}, cb);  // the only mixed pattern: tile 0 is K, the rest V
+    }
+    if (tail.logsig) {  // matchability head of the last block: one wave per 64 / NW tokens
+#pragma unroll 1
+      for (int tk = wave * (kFfnTok / NW); tk < (wave + 1) * (kFfnTok / NW); ++tk) {
         const h4_t v = *reinterpret_cast<const h4_t*>(s_x + tk * kFfnLd + lane * 4);
         float d = 0.f;
 #pragma unroll
@@ -591,6 +615,11 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       }
     }
   }
+}
+template <int NEXT_MT, bool HEADS, typename... A>
+static void launch_ffn_nw(int nw, dim3 grid, hipStream_t s, A... args) {
+  if (nw == 4) hipLaunchKernelGGL((k_lg_ffn<NEXT_MT, HEADS, 4>), grid, dim3(256), 0, s, args...);
+  else hipLaunchKernelGGL((k_lg_ffn<NEXT_MT, HEADS, 8>), grid, dim3(512), 0, s, args...);
 }
 // next == nullptr: plain FFN.  Otherwise the projection `next` (packed with ct = 32 * next_mt rows per wave) runs on
 // the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
@@ -604,9 +633,11 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.dbg = dbg;
   t.copies0 = w0.copies; t.stride0 = w0.copy_stride; t.copies3 = w3.copies; t.stride3 = w3.copy_stride;
   t.copiesp = 1; t.stridep = 0;
-  dim3 grid(tokens / kFfnTok), block(512);
+  // SUPERSLAM_HIP_FFN_WAVES=8|4 (default 8; 4 measured 6 % slower end to end): see k_lg_ffn
+  static const int nw = (getenv("SUPERSLAM_HIP_FFN_WAVES") && atoi(getenv("SUPERSLAM_HIP_FFN_WAVES")) == 4) ? 4 : 8;
+  dim3 grid(tokens / kFfnTok);
   if (!next) {
-    hipLaunchKernelGGL((k_lg_ffn<0, false>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    launch_ffn_nw<0, false>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
     return;
   }
   t.proj = token_args(*next, x, 256, nullptr, 0, d);
@@ -615,9 +646,9 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
   const int mt = next->cout / 256;  // rows per wave / 32: 768 -> 3, 512 -> 2, 256 -> 1
-  if (heads && mt == 3) hipLaunchKernelGGL((k_lg_ffn<3, true>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
-  else if (heads && mt == 2) hipLaunchKernelGGL((k_lg_ffn<2, true>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
-  else hipLaunchKernelGGL((k_lg_ffn<1, false>), grid, block, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  if (heads && mt == 3) launch_ffn_nw<3, true>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else if (heads && mt == 2) launch_ffn_nw<2, true>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else launch_ffn_nw<1, false>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
 }
 
 // ---------------------------------------------------------------------------------------------------

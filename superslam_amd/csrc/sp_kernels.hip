@@ -79,27 +79,44 @@ void launch_conv1a(const uint8_t* img, const float* w, const float* bias, _Float
 // Candidate key = (score bits << 32) | (h*W + w): descending key order == std::greater<pair<float,
 // pair<int,int>>> (SuperPoint.cc:703) because scores are positive floats.
 // ---------------------------------------------------------------------------------------------------
-constexpr int NT_H = 32, NT_W = 64, NHALO = 8, NLH = NT_H + 2 * NHALO, NLW = NT_W + 2 * NHALO, NLS = NLW + 1;
+constexpr int NT_H = 32, NT_W = 64, NHALO = 8, NLH = NT_H + 2 * NHALO, NLW = NT_W + 2 * NHALO, NLS = NLW + 4;
+constexpr int NMS_SLOTS = NT_H * NT_W / 256;  // pixels (candidate slots) per thread
 
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-template <int LOADER>
+// 4 sliding 9-wide maxima over 12 consecutive values (radius 4): 5 shared + 3 private max ops each.
+__device__ __forceinline__ void window9x4(const float (&v)[12], float (&o)[4]) {
+  const float c = fmaxf(max3(v[3], v[4], v[5]), max3(v[6], v[7], v[8]));
+  o[0] = fmaxf(c, max3(v[0], v[1], v[2]));
+  o[1] = fmaxf(c, max3(v[1], v[2], v[9]));
+  o[2] = fmaxf(c, max3(v[2], v[9], v[10]));
+  o[3] = fmaxf(c, max3(v[9], v[10], v[11]));
+}
+
+// RT = 4: the exporter's radius, register-window separable max with 16-byte LDS reads (the dynamic-radius loops
+// were LDS-latency-bound: ~20 us per workgroup).  RT = -1: any radius <= 8 (sship_nms stage API).
+template <int LOADER, int RT>
 __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
-  __shared__ float s_s[NLH * NLS];
-  __shared__ float s_r[NLH * NT_W];
-  __shared__ unsigned long long s_c[NT_H * NT_W];
+  // s_s: scores incl. halo [48][84]; s_r: row maxima [48][64]; the candidate list aliases both once they are dead
+  __shared__ __attribute__((aligned(16))) float s_buf[NLH * NLS + NLH * NT_W];
   __shared__ int s_cnt, s_base;
+  float* s_s = s_buf;
+  float* s_r = s_buf + NLH * NLS;
+  unsigned long long* s_c = reinterpret_cast<unsigned long long*>(s_buf);
+  static_assert(sizeof(s_buf) >= NT_H * NT_W * 8, "candidate list must fit the aliased buffers");
   const int tiles_x = (a.W + NT_W - 1) / NT_W, tiles_y = (a.H + NT_H - 1) / NT_H;
   int t = blockIdx.x;
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
   const int b = t / tiles_y;
   const int x0 = tx * NT_W - NHALO, y0 = ty * NT_H - NHALO;  // tile origin incl. halo (multiple of 8)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_cnt = 0;
   if constexpr (LOADER == 0) {
     const int Hc = a.H >> 3, Wc = a.W >> 3;
     const int cy0 = y0 >> 3, cx0 = x0 >> 3;  // may be -1
-    // 60 cells (6 x 10 incl. the halo ring) x 4 lanes: each lane owns 16 of the 64 position channels, the group
-    // of 4 shares max / sum through two DPP exchanges - one parallel pass, no per-cell serial loop.
+    // 60 cells (6 x 10 incl. the halo ring) x 4 lanes: each lane owns 16 of the 64 position channels (= 2 rows of
+    // the cell's 8 x 8 block), the group of 4 shares max / sum through two DPP exchanges.
     constexpr int NCELL = (NLH / 8) * (NLW / 8);
     if (tid < NCELL * 4) {
       const int cell = tid >> 2, qd = tid & 3;
@@ -127,14 +144,23 @@ __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
       m = fmaxf(m, __shfl_xor(m, 2, 64));
       float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - m); sum += v[i]; }
+      for (int i = 0; i < 16; ++i) { v[i] = __expf(v[i] - m); sum += v[i]; }
       sum += __shfl_xor(sum, 1, 64);
       sum += __shfl_xor(sum, 2, 64);
-      sum += expf(d - m);
+      sum += __expf(d - m);
+      const float inv = 1.0f / sum;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int c = qd * 16 + i;
-        s_s[(cyl * 8 + (c >> 3)) * NLS + cxl * 8 + (c & 7)] = in ? v[i] / sum : -INFINITY;
+      for (int r = 0; r < 2; ++r) {
+        float* dst = s_s + (cyl * 8 + qd * 2 + r) * NLS + cxl * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float4 o;
+          o.x = in ? v[r * 8 + h * 4 + 0] * inv : -INFINITY;
+          o.y = in ? v[r * 8 + h * 4 + 1] * inv : -INFINITY;
+          o.z = in ? v[r * 8 + h * 4 + 2] * inv : -INFINITY;
+          o.w = in ? v[r * 8 + h * 4 + 3] * inv : -INFINITY;
+          *reinterpret_cast<float4*>(dst + h * 4) = o;
+        }
       }
     }
   } else {
@@ -147,37 +173,90 @@ __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
     }
   }
   __syncthreads();
-  const int R = a.radius;
-  // row max over [x-R, x+R] for the 64 interior columns of all 48 rows
-  for (int i = tid; i < NLH * NT_W; i += 256) {
-    const int ly = i / NT_W, lx = (i % NT_W) + NHALO;
-    float m = -INFINITY;
-    for (int d = -R; d <= R; ++d) m = fmaxf(m, s_s[ly * NLS + lx + d]);
-    s_r[ly * NT_W + (lx - NHALO)] = m;
+  // ---- row maxima over [x-R, x+R] for the 64 interior columns of all 48 rows
+  if constexpr (RT == 4) {
+    for (int it = tid; it < NLH * (NT_W / 4); it += 256) {
+      const int row = it >> 4, seg = it & 15;
+      const float* p = s_s + row * NLS + NHALO - 4 + 4 * seg;
+      float v[12], o[4];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p + 4 * q);
+        v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+      }
+      window9x4(v, o);
+      *reinterpret_cast<float4*>(s_r + row * NT_W + 4 * seg) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  } else {
+    const int R = a.radius;
+    for (int i = tid; i < NLH * NT_W; i += 256) {
+      const int ly = i / NT_W, lx = (i % NT_W) + NHALO;
+      float m = -INFINITY;
+      for (int d = -R; d <= R; ++d) m = fmaxf(m, s_s[ly * NLS + lx + d]);
+      s_r[ly * NT_W + (lx - NHALO)] = m;
+    }
   }
-  if (tid == 0) s_cnt = 0;
   __syncthreads();
-  for (int i = tid; i < NT_H * NT_W; i += 256) {
-    const int iy = i / NT_W, ix = i % NT_W;
-    const int ly = iy + NHALO;
-    const int gy = y0 + ly, gx = x0 + NHALO + ix;
-    if (gy >= a.H || gx >= a.W) continue;
-    float m = -INFINITY;
-    for (int d = -R; d <= R; ++d) m = fmaxf(m, s_r[(ly + d) * NT_W + ix]);
-    const float s = s_s[ly * NLS + ix + NHALO];
-    const bool is_max = (R <= 0) || (s == m);
+  // ---- column maxima, survival test; every thread owns NMS_SLOTS pixels whose verdicts stay in registers
+  float sc[NMS_SLOTS];
+  unsigned keep = 0;
+  unsigned pix[NMS_SLOTS];
+  auto verdict = [&](int slot, int iy, int ix, float s, float m) {
+    const int gy = y0 + NHALO + iy, gx = x0 + NHALO + ix;
+    sc[slot] = s;
+    pix[slot] = (unsigned)(gy * a.W + gx);
+    if (gy >= a.H || gx >= a.W) return;
+    const bool is_max = (RT == 4) ? (s == m) : (a.radius <= 0 || s == m);
     const size_t o = ((size_t)b * a.H + gy) * a.W + gx;
     if (a.scores_raw_out) a.scores_raw_out[o] = s;
     if (a.scores_out) a.scores_out[o] = is_max ? s : 0.0f;
     if (a.cand && is_max && s >= a.thr_f && gy >= a.border && gy < a.H - a.border && gx >= a.border &&
-        gx < a.W - a.border) {
-      // workgroup-local compaction first: ONE global atomic per tile instead of one per candidate (the 16 per-image
-      // counters were the bottleneck: ~7k same-address L2 atomics per image serialise)
-      const int li = atomicAdd(&s_cnt, 1);
-      s_c[li] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(gy * a.W + gx);
+        gx < a.W - a.border)
+      keep |= 1u << slot;
+  };
+  if constexpr (RT == 4) {
+#pragma unroll
+    for (int k = 0; k < NMS_SLOTS / 4; ++k) {
+      const int it = tid + k * 256;
+      const int ix = it & 63, rg = it >> 6;  // 4 consecutive interior rows 4*rg .. 4*rg+3 of column ix
+      float v[12], o[4];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) v[q] = s_r[(4 * rg + NHALO - 4 + q) * NT_W + ix];
+      window9x4(v, o);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        verdict(k * 4 + q, 4 * rg + q, ix, s_s[(4 * rg + q + NHALO) * NLS + ix + NHALO], o[q]);
+    }
+  } else {
+    const int R = a.radius;
+#pragma unroll
+    for (int k = 0; k < NMS_SLOTS; ++k) {
+      const int i = tid + k * 256;
+      const int iy = i / NT_W, ix = i % NT_W;
+      float m = -INFINITY;
+      for (int d = -R; d <= R; ++d) m = fmaxf(m, s_r[(iy + NHALO + d) * NT_W + ix]);
+      verdict(k, iy, ix, s_s[(iy + NHALO) * NLS + ix + NHALO], m);
     }
   }
   if (a.cand) {
+    __syncthreads();  // s_s / s_r are dead: the candidate list takes their place
+    // workgroup-local compaction: one LDS atomic per wave, ONE global atomic per tile (per-candidate global atomics
+    // on the per-image counter serialise in L2)
+    const int mine = __popc(keep);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int wbase = 0;
+    if (lane == 63 && total) wbase = atomicAdd(&s_cnt, total);
+    wbase = __shfl(wbase, 63, 64);
+    int pos = wbase + incl - mine;
+#pragma unroll
+    for (int k = 0; k < NMS_SLOTS; ++k)
+      if (keep & (1u << k)) s_c[pos++] = ((unsigned long long)__float_as_uint(sc[k]) << 32) | pix[k];
     __syncthreads();
     const int n = s_cnt;
     if (tid == 0) s_base = n ? atomicAdd(&a.cand_count[b], n) : 0;
@@ -198,10 +277,14 @@ float threshold_as_float(double thr) {
 
 void launch_nms_tile(int loader, const NmsArgs& a, hipStream_t s) {
   const int tiles = a.B * ((a.W + NT_W - 1) / NT_W) * ((a.H + NT_H - 1) / NT_H);
-  if (loader == 0)
-    hipLaunchKernelGGL(k_nms_tile<0>, dim3(tiles), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles), dim3(256), 0, s, a);
+  const bool r4 = a.radius == 4;
+  if (loader == 0) {
+    if (r4) hipLaunchKernelGGL((k_nms_tile<0, 4>), dim3(tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_nms_tile<0, -1>), dim3(tiles), dim3(256), 0, s, a);
+  } else {
+    if (r4) hipLaunchKernelGGL((k_nms_tile<1, 4>), dim3(tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_nms_tile<1, -1>), dim3(tiles), dim3(256), 0, s, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -211,18 +294,39 @@ void launch_nms_tile(int loader, const NmsArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 
 
+constexpr int TOPK_CACHE = 8;  // keys per thread held in registers when the image has <= 8192 candidates
+
 __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
   __shared__ unsigned long long s_key[kMaxKp];
   __shared__ int s_hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_cnt;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int M = min(a.cand_count[b], a.cap);
   const int K = min(M, a.max_kp);
   if (a.n_cand_out && tid == 0) a.n_cand_out[b] = a.cand_count[b];
   if (tid == 0) a.n_out[b] = K;
   if (K == 0) return;
   const unsigned long long* cand = a.cand + (size_t)b * a.cap;
+  // the usual case (a few thousand candidates): every key is read from HBM once and stays in registers for the 8
+  // select passes and the compaction; larger sets stream from L2 each pass.
+  const bool cached = M <= TOPK_CACHE * 1024;
+  unsigned long long kr[TOPK_CACHE];
+#pragma unroll
+  for (int j = 0; j < TOPK_CACHE; ++j) kr[j] = (cached && tid + j * 1024 < M) ? cand[tid + j * 1024] : 0ull;
+  // one LDS atomic per wave when the whole wave agrees on the bin (the top digits of positive float scores nearly
+  // always do; 64 same-address atomics serialise)
+  auto count = [&](bool valid, int digit) {
+    const unsigned long long act = __ballot(valid);
+    if (!act) return;
+    const int d0 = __shfl(digit, __ffsll((long long)act) - 1, 64);
+    const unsigned long long same = __ballot(valid && digit == d0);
+    if (same == act) {
+      if (lane == __ffsll((long long)act) - 1) atomicAdd(&s_hist[d0], __popcll(act));
+    } else if (valid) {
+      atomicAdd(&s_hist[digit], 1);
+    }
+  };
   unsigned long long thresh = 0;
   if (M > K) {
     if (tid == 0) { s_prefix = 0; s_remaining = K; }
@@ -231,19 +335,41 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
       __syncthreads();
       const unsigned long long prefix = s_prefix;
       const int shift = 56 - 8 * pass;
-      for (int i = tid; i < M; i += 1024) {
-        const unsigned long long k = cand[i];
-        if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & 255)], 1);
+      if (cached) {
+#pragma unroll
+        for (int j = 0; j < TOPK_CACHE; ++j) {
+          const unsigned long long k = kr[j];
+          count(tid + j * 1024 < M && (pass == 0 || (k >> (shift + 8)) == prefix), (int)((k >> shift) & 255));
+        }
+      } else {
+        for (int i0 = 0; i0 < M; i0 += 1024) {
+          const int i = i0 + tid;
+          const unsigned long long k = i < M ? cand[i] : 0ull;
+          count(i < M && (pass == 0 || (k >> (shift + 8)) == prefix), (int)((k >> shift) & 255));
+        }
       }
       __syncthreads();
-      if (tid == 0) {
-        int rem = s_remaining, cum = 0, d = 255;
-        for (; d > 0; --d) {
-          if (cum + s_hist[d] >= rem) break;
-          cum += s_hist[d];
+      if (tid < 64) {
+        // descending-digit scan by one wave: lane l owns digits 255-4l .. 252-4l
+        int h[4], loc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = s_hist[255 - (4 * lane + j)]; loc += h[j]; }
+        int incl = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int up = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += up;
         }
-        s_remaining = rem - cum;
-        s_prefix = (prefix << 8) | (unsigned)d;
+        const int rem = s_remaining;
+        int c = incl - loc;
+        if (c < rem && rem <= incl) {
+          int d = 255 - 4 * lane;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (c + h[j] < rem && d == 255 - (4 * lane + j)) { c += h[j]; --d; }
+          s_remaining = rem - c;
+          s_prefix = (prefix << 8) | (unsigned)d;
+        }
       }
       __syncthreads();
     }
@@ -251,11 +377,24 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
   }
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  for (int i = tid; i < M; i += 1024) {
-    const unsigned long long k = cand[i];
-    if (k >= thresh) {
-      const int pos = atomicAdd(&s_cnt, 1);
-      if (pos < kMaxKp) s_key[pos] = k;
+  auto emit = [&](bool take, unsigned long long k) {
+    const unsigned long long act = __ballot(take);
+    if (!act) return;
+    int base = 0;
+    const int leader = __ffsll((long long)act) - 1;
+    if (lane == leader) base = atomicAdd(&s_cnt, __popcll(act));
+    base = __shfl(base, leader, 64);
+    const int pos = base + __popcll(act & ((1ull << lane) - 1ull));
+    if (take && pos < kMaxKp) s_key[pos] = k;
+  };
+  if (cached) {
+#pragma unroll
+    for (int j = 0; j < TOPK_CACHE; ++j) emit(tid + j * 1024 < M && kr[j] >= thresh, kr[j]);
+  } else {
+    for (int i0 = 0; i0 < M; i0 += 1024) {
+      const int i = i0 + tid;
+      const unsigned long long k = i < M ? cand[i] : 0ull;
+      emit(i < M && k >= thresh, k);
     }
   }
   int P2 = 1;
