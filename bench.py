@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=32, help="stereo pairs per step (per GPU), resident in HBM")
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step (per GPU), resident in HBM")
     ap.add_argument("--max-kp", type=int, default=600, help="superpoint.max_keypoints (600 = the KITTI YAML)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsuperslam_hip.so")
+# SUPERSLAM_HIP_LIBRARY: developer override (A/B builds of the same ABI, see build.build_variant)
+LIB_PATH = os.environ.get("SUPERSLAM_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsuperslam_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_IO, ERR_NOMEM, ERR_POOL_EXHAUSTED, ERR_NO_DEVICE = 1, 2, 3, 4, 5, 6

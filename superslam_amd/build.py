@@ -13,6 +13,10 @@ LIB = os.path.join(LIBDIR, "libsuperslam_hip.so")
 SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "lg_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
+# per-file flags.  lg_kernels: the attention softmax takes its running max over raw MFMA outputs; under IEEE NaN
+# semantics every fmaxf() operand is canonicalised first (2x the max instructions).  No NaN is ever produced there
+# (masked scores are -inf, never inf - inf), infinities keep their meaning.
+FILE_FLAGS = {"lg_kernels.hip": ["-fno-honor-nans"]}
 
 
 def _newest(paths):
@@ -32,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIBDIR, "obj", src.replace(".hip", ".o"))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), hdr_time):
-            jobs.append([hipcc, *FLAGS, "-c", sp, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", sp, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -50,5 +54,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, extra_flags) -> str:
+    """Developer A/B builds: same sources + extra -D flags -> lib/variants/<name>.so (load via SUPERSLAM_HIP_LIBRARY)."""
+    vdir = os.path.join(LIBDIR, "variants")
+    odir = os.path.join(vdir, "obj_" + name)
+    os.makedirs(odir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+
+    def one(src):
+        obj = os.path.join(odir, src.replace(".hip", ".o"))
+        r = subprocess.run([hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stdout + r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(one, SOURCES))
+    out = os.path.join(vdir, name + ".so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], check=True)
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -22,6 +22,11 @@
 #include "igemm.h"
 #include "kernels.h"
 
+// compile-time ablation of the MFMA loop (build.py --variant): 1 no A-fragment reads, 2 no B-fragment reads, 4 no sched pins
+#ifndef SSHIP_STRIP_ABL
+#define SSHIP_STRIP_ABL 0
+#endif
+
 namespace sship {
 
 struct StripArgs {
@@ -236,22 +241,27 @@ __global__ __launch_bounds__(512) void conv3x3_strip(StripArgs p) {
       h8_t fa[2][MT], fb[2][2];
       auto load_frags = [&](int idx, int buf) {
         const int tap = idx >> 2, ks = idx & 3, ky = tap / 3, kx = tap - ky * 3;
+        if (!(SSHIP_STRIP_ABL & 1) || idx == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) fa[buf][m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
+          for (int m = 0; m < MT; ++m) fa[buf][m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
+        }
+        if (!(SSHIP_STRIP_ABL & 2) || idx == 0) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-          fb[buf][n] = *reinterpret_cast<const h8_t*>(ib + ((n + ky) * S_TWH + kx) * kCP + ks * 16);
+          for (int n = 0; n < 2; ++n)
+            fb[buf][n] = *reinterpret_cast<const h8_t*>(ib + ((n + ky) * S_TWH + kx) * kCP + ks * 16);
+        }
       };
       load_frags(0, 0);
 #pragma unroll
       for (int idx = 0; idx < 36; ++idx) {
         if (idx + 1 < 36) load_frags(idx + 1, (idx + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(SSHIP_STRIP_ABL & 4)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(fa[idx & 1][m], fb[idx & 1][n], acc[m][n]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = mfma32(fa[(SSHIP_STRIP_ABL & 1) ? 0 : (idx & 1)][m], fb[(SSHIP_STRIP_ABL & 2) ? 0 : (idx & 1)][n], acc[m][n]);
+        if (!(SSHIP_STRIP_ABL & 4)) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- epilogue: bias + ReLU (+ 2x2 max-pool), fp16 channels-last ----

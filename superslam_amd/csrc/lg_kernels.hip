@@ -135,6 +135,16 @@ hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope
 // QT query tiles (32 queries each) per wave share every K / V^T fragment load: the kernel is bound by the L2 -> CU
 // fragment traffic (each workgroup streams the whole K/V of its (sequence, head) once: QT = 1 moved 840 MB per launch
 // at P = 32), so two query tiles per wave halve it at the cost of 2x accumulator registers.
+// v_max3_f32.  This file is built with -fno-honor-nans (build.py): without it fmaxf() canonicalises every MFMA output
+// first (one extra v_max_f32 x, x per score).  No inline asm here: hipcc does not insert the MFMA -> VALU wait states
+// in front of asm operands.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// max(x, x of lane ^ 32)
+__device__ __forceinline__ float max_xor32(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = {lo half, lo half}, r[1] = {hi, hi}
+  return max3f(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[1]));
+}
 template <int QT>
 __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                          const _Float16* __restrict__ vt, const int* __restrict__ lens,
@@ -203,15 +213,19 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
       if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
+        int kb = k0 + 4 * hh;
+        asm volatile("" : "+v"(kb));  // keeps the 16 key indices inside the branch (hipcc hoisted them into every iteration)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= nk) st[r] = -INFINITY;
+          if (kb + (r & 3) + 8 * (r >> 2) >= nk) st[r] = -INFINITY;
       }
-      float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+      // running max on v_max3_f32 (8 instructions; fmaxf() first canonicalises every MFMA output: 16 more), and the
+      // lane^32 exchange on v_permlane32_swap instead of an LDS round trip (ds_bpermute + lgkmcnt(0) per query tile)
+      float tmax = max3f(st[0], st[1], st[2]);
+      tmax = max3f(tmax, st[3], st[4]);
 #pragma unroll
-      for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[r], st[r + 1]), fmaxf(st[r + 2], st[r + 3])));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m[t], tmax);
+      for (int r = 5; r < 15; r += 2) tmax = max3f(tmax, st[r], st[r + 1]);
+      const float m_new = max3f(m[t], st[15], max_xor32(max3f(tmax, st[15], st[15])));
       // the softmax is VALU-bound at head_dim 64: rescale the 32 output accumulators only when some query's running
       // max actually moved (exact - not the lossy defer-max trick)
       if (__any(m_new > m[t])) {
@@ -321,53 +335,93 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
 //     the next layer's Wqkv after a CrossBlock FFN, final_proj + matchability after the last one) runs in the same
 //     launch on the 64-token tile that is already on chip: wave w owns NEXT_MT*32 output rows, K = 256, epilogue =
 //     the igemm epilogue of that projection (EpiHeads / plain fp16).
-constexpr int kFfnTok = 64, kFfnLd = 520;
+constexpr int kFfnLd = 520;
 struct FfnTail {
+  int ntiles;                               // token tiles of the launch (the kernel is persistent: tile = blockIdx.x + k gridDim.x)
   int dbg;                                  // ablation (SSHIP_FFN_DBG): 1 skip ffn.0 MFMAs, 2 skip LN/GELU math, 4 skip ffn.3, 8 skip tail
   int copies0, copies3, copiesp;            // weight replicas (workgroup b reads replica b % copies)
   size_t stride0, stride3, stridep;         // halfs between replicas
   IgemmArgs proj;          // epilogue arguments of the fused projection (wpack/bias/outputs/rope/np/flags/cout/H)
+  unsigned long long* trace;  // SSHIP_FFN_TRACE: [workgroup][wave][12] shader-clock stamps of the workgroup's 2nd tile
   const float* match_w;    // final block only: matchability weights [256] ...
   float match_b;
   float* logsig;           // ... -> logsigmoid(z) per token
 };
-// NW = waves per workgroup.  8: one 512-thread workgroup per CU (the kernel needs > 128 VGPRs), every wave owns one
-// row block per GEMM.  4: two independent 256-thread workgroups per CU, every wave owns RB = 2 row blocks and runs them
-// back to back on the same LDS token tile - the staging / LayerNorm barriers / epilogue stores of one workgroup
-// overlap the MFMA phases of the other instead of idling the CU.  Same packed weights, same arithmetic order.
-template <int NEXT_MT, bool HEADS, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
+// NT = 32-token N-tiles per workgroup.  Every weight fragment a wave streams from L2 feeds NT MFMAs; at NT = 2 the
+// three GEMMs need 64 B/clk/CU of L2 -> L1 bandwidth to keep the matrix pipe busy (= the TCP's peak, so the kernel
+// was bound by the weight stream: 1.18 MB per 64 tokens).  NT = 4 halves the stream per token (throughput batches);
+// NT = 2 keeps more workgroups in flight for a few pairs (latency mode).
+template <int NEXT_MT, bool HEADS, int NT>
+__global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                 const float* __restrict__ b0, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
                                                 const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
-  constexpr int RB = 8 / NW, NTHR = NW * 64;
-  constexpr int G0 = 8 / RB;    // ffn.0 k-steps per register-prefetch group
-  constexpr int G3 = 16 / RB;   // ffn.3 k-steps per group
-  __shared__ __attribute__((aligned(16))) _Float16 s_x[kFfnTok * kFfnLd];
-  __shared__ float s_red[NW][kFfnTok];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
-  const size_t t0 = (size_t)blockIdx.x * kFfnTok;
-  for (int u = tid; u < kFfnTok * 64; u += NTHR) {
-    const int tok = u >> 6, part = u & 63;
-    const _Float16* src = part < 32 ? x + (t0 + tok) * 256 + part * 8 : ctx + (t0 + tok) * 256 + (part - 32) * 8;
-    *reinterpret_cast<uint4*>(s_x + tok * kFfnLd + part * 8) = (tail.dbg & 16) ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(src);
-  }
+  constexpr int NTOK = NT * 32;
+  constexpr int G0 = NT == 2 ? 8 : 4;  // ffn.0 k-steps per register-prefetch group (acc takes 32 NT registers)
+  constexpr int XBUF = NTOK * kFfnLd;  // halfs per token-tile buffer
+  extern __shared__ __attribute__((aligned(16))) char ffn_smem[];
+  _Float16* s_xbuf = reinterpret_cast<_Float16*>(ffn_smem);                                   // [NBUF][NTOK][kFfnLd]
+  float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_xbuf + (NT == 2 ? 2 : 1) * XBUF);  // [8][NTOK]
+  // Token-tile staging by LDS-DMA (global_load_lds_dwordx4): one instruction per token row - lanes 0..31 fetch the 32
+  // 16-byte units of x[token], lanes 32..63 those of ctx[token]; the row lands lane-linear at its (padded) LDS row.
+  // No staging registers, no ds_write pass, and - with two tile buffers (NT = 2) - the NEXT tile streams in while this
+  // one is in its GELU / ffn.3 phases.  The DMA is invisible to hipcc's waitcnt bookkeeping: its completion is awaited
+  // explicitly (vmcnt(0) where no weight prefetch is in flight), then a barrier, then the reads.
+  auto stage_tile = [&](int tile, _Float16* dst, int wave, int lane) {
+    if (tail.dbg & 16) return;
+    const size_t tt = (size_t)tile * NTOK;
+#pragma unroll
+    for (int k = 0; k < NTOK / 8; ++k) {
+      const int tok = wave + 8 * k;
+      const _Float16* gsrc = (lane < 32 ? x + (tt + tok) * 256 + lane * 8 : ctx + (tt + tok) * 256 + (lane - 32) * 8);
+      const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst + tok * kFfnLd));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  const int tile0 = blockIdx.x;
+  if (tile0 >= tail.ntiles) return;
+  stage_tile(tile0, s_xbuf, threadIdx.x >> 6, threadIdx.x & 63);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // ---- ffn.0 : row blocks cb = wave*RB + rb, rows [64 cb, +64) x 64 tokens, K = 512 ----
-  f16x_t acc[RB][2][2];
+  int it = 0;
+#pragma unroll 1
+  for (int tile = tile0; tile < tail.ntiles; tile += gridDim.x, ++it) {
+  _Float16* s_x = s_xbuf + (NT == 2 ? (it & 1) : 0) * XBUF;
+  _Float16* s_xn = s_xbuf + (NT == 2 ? ((it + 1) & 1) : 0) * XBUF;
+  const bool has_next = tile + (int)gridDim.x < tail.ntiles;
+  const size_t t0 = (size_t)tile * NTOK;
+  // Everything below that does not depend on the tile (weight fragments, biases, LayerNorm parameters) is loop
+  // invariant: LICM would hoist those loads out of the tile loop and spill hundreds of registers.  An opaque zero
+  // added to every such pointer keeps them inside the iteration.
+  int zero = 0;
+  asm volatile("" : "+s"(zero));
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // same for the lane-dependent address arithmetic (dozens of 64-bit offsets)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const _Float16 *w0q = w0p + zero, *w3q = w3p + zero;
+  const float *b0q = b0 + zero, *gq = gamma + zero, *beq = beta + zero, *b3q = b3 + zero;
+  IgemmArgs pj = tail.proj;
+  pj.wpack += zero; pj.bias += zero;
+  const float* mwq = tail.match_w + zero;
+  const _Float16* bfp = s_x + j * kFfnLd + hh * 8;  // B fragment of N-tile n, k-step ks: bfp + n*32*kFfnLd + ks*16
+  auto stamp = [&](int slot) {
+    if (tail.trace && it == 1 && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
+  };
+  stamp(0);
+  // ---- ffn.0 : rows [64 wave, +64) x NTOK tokens, K = 512 ----
+  f16x_t acc[2][NT];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rb][m][n][r] = 0.f;
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  {
     // Weight fragments stream from L2 (no reuse between waves); keep TWO groups of G0 k-steps in flight in registers
-    // so ~1k cycles of L2 latency are covered by the MFMAs of the previous group and the co-resident waves.
-    const _Float16* wp = w0p + (blockIdx.x % tail.copies0) * tail.stride0 + (size_t)(wave * RB + rb) * (32 * 2 * 512) + lane * 8;  // packed [cb][k16][mt][lane][8]
+    // so ~1k cycles of L2 latency are covered by the MFMAs of the previous group and the co-resident wave.
+    const _Float16* wp = w0q + (blockIdx.x % tail.copies0) * tail.stride0 + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
     h8_t ab[2][G0][2];
 #pragma unroll
     for (int i = 0; i < G0; ++i) {
@@ -388,190 +442,214 @@ __global__ __launch_bounds__(NW * 64, 2) void k_lg_ffn(const _Float16* __restric
 #pragma unroll
       for (int i = 0; i < G0; ++i) {
         const int ks = grp * G0 + i;
-        const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
-        const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
-        acc[rb][0][0] = mfma32(ab[grp & 1][i][0], bf0, acc[rb][0][0]);
-        acc[rb][0][1] = mfma32(ab[grp & 1][i][0], bf1, acc[rb][0][1]);
-        acc[rb][1][0] = mfma32(ab[grp & 1][i][1], bf0, acc[rb][1][0]);
-        acc[rb][1][1] = mfma32(ab[grp & 1][i][1], bf1, acc[rb][1][1]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const h8_t bf = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + ks * 16);
+          acc[0][n] = mfma32(ab[grp & 1][i][0], bf, acc[0][n]);
+          acc[1][n] = mfma32(ab[grp & 1][i][1], bf, acc[1][n]);
+        }
       }
     }
   }
-  // ---- bias, LayerNorm(512) over the row dimension (spread over regs, lane^32 and the waves), GELU ----
-  float sum[2] = {0.f, 0.f};
+  stamp(1);
+  // ---- bias, LayerNorm(512) over the row dimension (spread over regs, lane^32 and the 8 waves), GELU ----
+  float sum[NT];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int n = 0; n < NT; ++n) sum[n] = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(b0 + (wave * RB + rb) * 64 + m * 32 + hh * 4 + g * 8);
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *reinterpret_cast<const float4*>(b0q + wave * 64 + m * 32 + hh * 4 + g * 8);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          acc[rb][m][n][4 * g + 0] += bv.x; acc[rb][m][n][4 * g + 1] += bv.y; acc[rb][m][n][4 * g + 2] += bv.z; acc[rb][m][n][4 * g + 3] += bv.w;
-          sum[n] += (acc[rb][m][n][4 * g + 0] + acc[rb][m][n][4 * g + 1]) + (acc[rb][m][n][4 * g + 2] + acc[rb][m][n][4 * g + 3]);
-        }
+      for (int n = 0; n < NT; ++n) {
+        acc[m][n][4 * g + 0] += bv.x; acc[m][n][4 * g + 1] += bv.y; acc[m][n][4 * g + 2] += bv.z; acc[m][n][4 * g + 3] += bv.w;
+        sum[n] += (acc[m][n][4 * g + 0] + acc[m][n][4 * g + 1]) + (acc[m][n][4 * g + 2] + acc[m][n][4 * g + 3]);
       }
-  float mean[2], rstd[2];
+    }
+  float mean[NT], rstd[NT];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NT; ++n) {
     sum[n] += __shfl_xor(sum[n], 32, 64);
     if (hh == 0) s_red[wave][n * 32 + j] = sum[n];
   }
   __syncthreads();
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NT; ++n) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t += s_red[w][n * 32 + j];
+    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
     mean[n] = t * (1.0f / 512.0f);
   }
   __syncthreads();
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NT; ++n) {
     float sq = 0.f;
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float dlt = acc[rb][m][n][r] - mean[n]; sq += dlt * dlt; }
+      for (int r = 0; r < 16; ++r) { const float dlt = acc[m][n][r] - mean[n]; sq += dlt * dlt; }
     sq += __shfl_xor(sq, 32, 64);
     if (hh == 0) s_red[wave][n * 32 + j] = sq;
   }
   __syncthreads();
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NT; ++n) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t += s_red[w][n * 32 + j];
+    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
     rstd[n] = rsqrtf(t * (1.0f / 512.0f) + 1e-5f);
   }
+  stamp(2);
+  // every wave has passed the LayerNorm barriers, i.e. finished the previous tile: its buffer takes the next tile.
+  // Issued here because no weight prefetch is in flight (an older DMA would sit in front of it in the in-order vmcnt
+  // queue) and the GELU math + ffn.3 that follow cover the HBM latency.
+  if (NT == 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);
   // every wave has passed two barriers since its last read of s_x: the tile can be overwritten with the hidden tile
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int g = 0; g < 4; ++g) {
+      const int c = wave * 64 + m * 32 + hh * 4 + g * 8;
+      const float4 gv = *reinterpret_cast<const float4*>(gq + c);
+      const float4 be = *reinterpret_cast<const float4*>(beq + c);
+      const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = (wave * RB + rb) * 64 + m * 32 + hh * 4 + g * 8;
-        const float4 gv = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 be = *reinterpret_cast<const float4*>(beta + c);
-        const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {be.x, be.y, be.z, be.w};
+      for (int n = 0; n < NT; ++n) {
+        float o[4];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float y = (acc[rb][m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
-            o[e] = (tail.dbg & 2) ? y : 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
-          }
-          *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
+        for (int e = 0; e < 4; ++e) {
+          const float y = (acc[m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
+          o[e] = (tail.dbg & 2) ? y : 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
         }
+        *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
       }
+    }
+  stamp(3);
   __syncthreads();
-  // ---- ffn.3 : row blocks cb = wave*RB + rb, rows [32 cb, +32) x 64 tokens, K = 512, + residual ----
-  f16x_t ac2[RB][2];
+  stamp(4);
+  // ---- ffn.3 : rows [32 wave, +32) x NTOK tokens, K = 512, + residual ----
+  f16x_t ac2[NT];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int n = 0; n < NT; ++n)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int r = 0; r < 16; ++r) ac2[n][r] = 0.f;
+  {
+    const _Float16* wp = w3q + (blockIdx.x % tail.copies3) * tail.stride3 + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
+    h8_t a3[2][16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ac2[rb][n][r] = 0.f;
+    for (int i = 0; i < 16; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const _Float16* wp = w3p + (blockIdx.x % tail.copies3) * tail.stride3 + (size_t)(wave * RB + rb) * (32 * 512) + lane * 8;  // packed [cb][k16][mt = 0][lane][8]
-    h8_t a3[2][G3];
-#pragma unroll
-    for (int i = 0; i < G3; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
-#pragma unroll
-    for (int grp = 0; grp < 32 / G3; ++grp) {
+    for (int grp = 0; grp < 2; ++grp) {
       if (tail.dbg & 4) break;
-      if (grp + 1 < 32 / G3) {
+      if (grp == 0) {
 #pragma unroll
-        for (int i = 0; i < G3; ++i) a3[(grp + 1) & 1][i] = *reinterpret_cast<const h8_t*>(wp + ((grp + 1) * G3 + i) * 512);
+        for (int i = 0; i < 16; ++i) a3[1][i] = *reinterpret_cast<const h8_t*>(wp + (16 + i) * 512);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < G3; ++i) {
-        const int ks = grp * G3 + i;
-        const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
-        const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
-        ac2[rb][0] = mfma32(a3[grp & 1][i], bf0, ac2[rb][0]);
-        ac2[rb][1] = mfma32(a3[grp & 1][i], bf1, ac2[rb][1]);
+      for (int i = 0; i < 16; ++i) {
+        const int ks = grp * 16 + i;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const h8_t bf = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + ks * 16);
+          ac2[n] = mfma32(a3[grp][i], bf, ac2[n]);
+        }
       }
     }
   }
+  stamp(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed (before the barrier below / the next tile's first barrier)
   if constexpr (NEXT_MT > 0) __syncthreads();  // all waves are done reading the hidden tile: s_x gets the new x
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int g = 0; g < 4; ++g) {
+    const int c = wave * 32 + hh * 4 + g * 8;
+    const float4 bv = *reinterpret_cast<const float4*>(b3q + c);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = (wave * RB + rb) * 32 + hh * 4 + g * 8;
-      const float4 bv = *reinterpret_cast<const float4*>(b3 + c);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
-        if (tail.dbg & 64) continue;
-        const h4_t o = *px;
-        const h4_t xn = to_h4((float)o[0] + (ac2[rb][n][4 * g + 0] + bv.x), (float)o[1] + (ac2[rb][n][4 * g + 1] + bv.y),
-                              (float)o[2] + (ac2[rb][n][4 * g + 2] + bv.z), (float)o[3] + (ac2[rb][n][4 * g + 3] + bv.w));
-        *px = xn;
-        if constexpr (NEXT_MT > 0) *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = xn;
-      }
+    for (int n = 0; n < NT; ++n) {
+      h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
+      if (tail.dbg & 64) continue;
+      const h4_t o = *px;
+      const h4_t xn = to_h4((float)o[0] + (ac2[n][4 * g + 0] + bv.x), (float)o[1] + (ac2[n][4 * g + 1] + bv.y),
+                            (float)o[2] + (ac2[n][4 * g + 2] + bv.z), (float)o[3] + (ac2[n][4 * g + 3] + bv.w));
+      *px = xn;
+      if constexpr (NEXT_MT > 0) *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = xn;
     }
+  }
+  stamp(6);
   if constexpr (NEXT_MT > 0) {
     __syncthreads();
-    // ---- fused next projection: row blocks cb = wave*RB + rb, rows [NEXT_MT*32*cb, +NEXT_MT*32) x 64 tokens, K = 256 ----
+    stamp(7);
+    // ---- fused next projection: rows [NEXT_MT*32*wave, +NEXT_MT*32) x NTOK tokens, K = 256 ----
+    f16x_t ac3[NEXT_MT][NT];
+#pragma unroll
+    for (int m = 0; m < NEXT_MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
+    const _Float16* wp = pj.wpack + (blockIdx.x % tail.copiesp) * tail.stridep + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
     // M-tiles of the V segment run with SWAPPED operands (A = token tile, B = weights): the accumulator then holds
     // D[token][channel] with lane = channel and 8 consecutive registers = the 8 keys of one PV A-fragment unit, so V^T is
     // written in fragment order with one 16-byte store per lane (the 2-byte transposing stores it replaces were ~16x
     // write-amplified and dominated the kernel's non-MFMA time).
-    const int t_seg = (tail.proj.flags >> 4) & 0xf;
-    // which of a row block's M-tiles belong to the V segment is wave-uniform; the loop is instantiated per pattern
-    // (VMASK bit m = tile m is V) so its body stays branch-free: self Wqkv (3 tiles/block): 000, 110 (block 5), 111;
-    // cross [to_qk|to_v] (2 tiles/block): 00, 11.
-    auto run_tail = [&](auto vmask_c, int cb) {
+    const int t_seg = (pj.flags >> 4) & 0xf;
+    // which of this wave's M-tiles belong to the V segment is wave-uniform; the loop is instantiated per pattern
+    // (VMASK bit m = tile m is V) so its body stays branch-free: self Wqkv (3 tiles/wave): 000, 110 (wave 5), 111;
+    // cross [to_qk|to_v] (2 tiles/wave): 00, 11.
+    auto run_tail = [&](auto vmask_c) {
       constexpr int VMASK = decltype(vmask_c)::value;
-      f16x_t ac3[NEXT_MT][2];
+      // weight fragments: two groups of GT k-steps in flight in registers, pinned above the MFMAs of the previous
+      // group (a plain unrolled loop made hipcc wait for every fragment right before its MFMA: 28k clocks for 96 MFMAs)
+      constexpr int GT = NT == 2 ? 4 : 2;
+      h8_t at[2][GT][NEXT_MT];
 #pragma unroll
-      for (int m = 0; m < NEXT_MT; ++m)
+      for (int i = 0; i < GT; ++i)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < NEXT_MT; ++m) at[0][i][m] = *reinterpret_cast<const h8_t*>(wp + (i * NEXT_MT + m) * 512);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
-      const _Float16* wp = tail.proj.wpack + (blockIdx.x % tail.copiesp) * tail.stridep + (size_t)cb * (16 * NEXT_MT * 512) + lane * 8;  // [cb][k16][mt][lane][8]
-#pragma unroll 16
-      for (int ks = 0; ks < 16; ++ks) {
+      for (int grp = 0; grp < 16 / GT; ++grp) {
         if (tail.dbg & 8) break;
-        const h8_t bf0 = *reinterpret_cast<const h8_t*>(s_x + j * kFfnLd + ks * 16 + hh * 8);
-        const h8_t bf1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kFfnLd + ks * 16 + hh * 8);
+        if (grp + 1 < 16 / GT) {
 #pragma unroll
-        for (int m = 0; m < NEXT_MT; ++m) {
-          const h8_t a = *reinterpret_cast<const h8_t*>(wp + (ks * NEXT_MT + m) * 512);
-          if ((VMASK >> m) & 1) {
-            ac3[m][0] = mfma32(bf0, a, ac3[m][0]);
-            ac3[m][1] = mfma32(bf1, a, ac3[m][1]);
-          } else {
-            ac3[m][0] = mfma32(a, bf0, ac3[m][0]);
-            ac3[m][1] = mfma32(a, bf1, ac3[m][1]);
+          for (int i = 0; i < GT; ++i)
+#pragma unroll
+            for (int m = 0; m < NEXT_MT; ++m)
+              at[(grp + 1) & 1][i][m] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * GT + i) * NEXT_MT + m) * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < GT; ++i) {
+          const int ks = grp * GT + i;
+          h8_t bf[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + ks * 16);
+#pragma unroll
+          for (int m = 0; m < NEXT_MT; ++m) {
+            const h8_t a = at[grp & 1][i][m];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              if ((VMASK >> m) & 1) ac3[m][n] = mfma32(bf[n], a, ac3[m][n]);
+              else ac3[m][n] = mfma32(a, bf[n], ac3[m][n]);
+            }
           }
         }
       }
+      stamp(8);
       if (tail.dbg & 32) return;
       if constexpr (HEADS) {
-        const int NP = tail.proj.np, nt32 = NP >> 5;
+        const int NP = pj.np, nt32 = NP >> 5;
 #pragma unroll
         for (int m = 0; m < NEXT_MT; ++m) {
-          const int R0 = (cb * NEXT_MT + m) * 32;  // first output row of this M-tile
+          const int R0 = (wave * NEXT_MT + m) * 32;  // first output row of this M-tile
           if ((VMASK >> m) & 1) {
             const int hd = (R0 >> 6) & 3, mth = (R0 >> 5) & 1;  // head, 32-channel half of the head
-            const float bv = tail.proj.bias[R0 + j];
+            const float bv = pj.bias[R0 + j];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
               const size_t token = t0 + n * 32;
               const int sq = (int)(token / NP), kt = (int)(token - (size_t)sq * NP) >> 5;
-              _Float16* dst = static_cast<_Float16*>(tail.proj.out2) + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048 + lane * 8;
+              _Float16* dst = static_cast<_Float16*>(pj.out2) + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048 + lane * 8;
 #pragma unroll
               for (int kk = 0; kk < 2; ++kk) {
                 h8_t o;
@@ -581,45 +659,85 @@ __global__ __launch_bounds__(NW * 64, 2) void k_lg_ffn(const _Float16* __restric
               }
             }
           } else {
-            f16x_t one[1][2] = {{ac3[m][0], ac3[m][1]}};
-            EpiHeads::template run<1, 2>(tail.proj, one, 0, (int)(t0 >> 5), j, R0, hh);
+            f16x_t (&one)[1][NT] = *reinterpret_cast<f16x_t (*)[1][NT]>(&ac3[m]);
+            EpiHeads::template run<1, NT>(pj, one, 0, (int)(t0 >> 5), j, R0, hh);
           }
         }
       } else {
-        EpiF16<false, false>::template run<NEXT_MT, 2>(tail.proj, ac3, 0, (int)(t0 >> 5), j, cb * NEXT_MT * 32, hh);
+        EpiF16<false, false>::template run<NEXT_MT, NT>(pj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
       }
     };
-    constexpr int FULL = (1 << NEXT_MT) - 1;
-#pragma unroll 1
-    for (int rb = 0; rb < RB; ++rb) {
-      const int cb = wave * RB + rb;
-      int vmask = 0;
-      if constexpr (HEADS) {
+    int vmask = 0;
+    if constexpr (HEADS) {
 #pragma unroll
-        for (int m = 0; m < NEXT_MT; ++m) vmask |= ((((cb * NEXT_MT + m) >> 3) == t_seg) ? 1 : 0) << m;
-      }
-      vmask = __builtin_amdgcn_readfirstlane(vmask);
-      if (vmask == 0) run_tail(std::integral_constant<int, 0>{}, cb);
-      else if (vmask == FULL) run_tail(std::integral_constant<int, FULL>{}, cb);
-      else run_tail(std::integral_constant<int, (FULL & ~1)>{}, cb);  // the only mixed pattern: tile 0 is K, the rest V
+      for (int m = 0; m < NEXT_MT; ++m) vmask |= ((((wave * NEXT_MT + m) >> 3) == t_seg) ? 1 : 0) << m;
     }
-    if (tail.logsig) {  // matchability head of the last block: one wave per 64 / NW tokens
+    vmask = __builtin_amdgcn_readfirstlane(vmask);
+    constexpr int FULL = (1 << NEXT_MT) - 1;
+    if (vmask == 0) run_tail(std::integral_constant<int, 0>{});
+    else if (vmask == FULL) run_tail(std::integral_constant<int, FULL>{});
+    else run_tail(std::integral_constant<int, (FULL & ~1)>{});  // the only mixed pattern: tile 0 is K, the rest V
+    if (tail.logsig) {  // matchability head of the last block: one wave per NTOK / 8 tokens
 #pragma unroll 1
-      for (int tk = wave * (kFfnTok / NW); tk < (wave + 1) * (kFfnTok / NW); ++tk) {
+      for (int tk = wave * (NTOK / 8); tk < (wave + 1) * (NTOK / 8); ++tk) {
         const h4_t v = *reinterpret_cast<const h4_t*>(s_x + tk * kFfnLd + lane * 4);
         float d = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d += (float)v[e] * tail.match_w[lane * 4 + e];
+        for (int e = 0; e < 4; ++e) d += (float)v[e] * mwq[lane * 4 + e];
         const float z = wave_sum(d) + tail.match_b;
         if (lane == 0) tail.logsig[t0 + tk] = fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
       }
     }
   }
+  stamp(9);
+  if (NT != 2 && has_next) {  // single tile buffer: synchronous restage
+    __syncthreads();
+    stage_tile(tile + gridDim.x, s_xn, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (has_next) __syncthreads();  // DMA data (awaited per wave above) visible to every wave; s_red / tile buffers quiescent
+  stamp(10);
+  }  // tile loop
+}
+template <int NEXT_MT, bool HEADS, int NT, typename... A>
+static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
+  constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 8 * NT * 32 * 4;
+  static_assert(smem <= 163840, "LDS budget");
+  auto kern = k_lg_ffn<NEXT_MT, HEADS, NT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int ntiles = tokens / (NT * 32);
+  hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), smem, s, args...);  // one persistent workgroup per CU
+  return hipGetLastError();
+}
+// SSHIP_FFN_TRACE=1 (developer aid): mean shader-clock duration of every phase of a workgroup's second tile.
+static void ffn_trace_report(unsigned long long* dev, int nwg, int next_mt, hipStream_t s) {
+  std::vector<unsigned long long> h((size_t)nwg * 8 * 12);
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost);
+  static const char* names[10] = {"ffn.0", "LN stats", "DMA issue+GELU", "barrier", "ffn.3", "vmcnt+barrier+residual", "barrier", "tail MFMA", "tail epilogue", "end barrier"};
+  double sum[10] = {0}; long cnt = 0;
+  for (int w = 0; w < nwg * 8; ++w) {
+    const unsigned long long* t = h.data() + (size_t)w * 12;
+    if (!t[0] || !t[10]) continue;
+    for (int i = 0; i < 10; ++i) sum[i] += (double)(t[i + 1] > t[i] ? t[i + 1] - t[i] : 0);
+    ++cnt;
+  }
+  if (!cnt) return;
+  fprintf(stderr, "[ffn trace next_mt=%d, %ld waves]", next_mt, cnt);
+  double tot = 0;
+  for (int i = 0; i < 10; ++i) { fprintf(stderr, " %s=%.0f", names[i], sum[i] / cnt); tot += sum[i] / cnt; }
+  fprintf(stderr, " | tile=%.0f clk\n", tot);
 }
 template <int NEXT_MT, bool HEADS, typename... A>
-static void launch_ffn_nw(int nw, dim3 grid, hipStream_t s, A... args) {
-  if (nw == 4) hipLaunchKernelGGL((k_lg_ffn<NEXT_MT, HEADS, 4>), grid, dim3(256), 0, s, args...);
-  else hipLaunchKernelGGL((k_lg_ffn<NEXT_MT, HEADS, 8>), grid, dim3(512), 0, s, args...);
+static hipError_t launch_ffn(int nt, int tokens, hipStream_t s, A... args) {
+  (void)nt;  // only the 64-token tile is instantiated: 128 tokens measured 9 % slower end to end (1.25 tiles per CU at
+             // 32 pairs, single tile buffer) and no longer fits the register file next to the prefetch buffers
+  return launch_ffn_nt<NEXT_MT, HEADS, 2>(tokens, s, args...);
 }
 // next == nullptr: plain FFN.  Otherwise the projection `next` (packed with ct = 32 * next_mt rows per wave) runs on
 // the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
@@ -633,11 +751,19 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.dbg = dbg;
   t.copies0 = w0.copies; t.stride0 = w0.copy_stride; t.copies3 = w3.copies; t.stride3 = w3.copy_stride;
   t.copiesp = 1; t.stridep = 0;
-  // SUPERSLAM_HIP_FFN_WAVES=8|4 (default 8; 4 measured 6 % slower end to end): see k_lg_ffn
-  static const int nw = (getenv("SUPERSLAM_HIP_FFN_WAVES") && atoi(getenv("SUPERSLAM_HIP_FFN_WAVES")) == 4) ? 4 : 8;
-  dim3 grid(tokens / kFfnTok);
+  const int nt = 2;  // 32-token N-tiles per workgroup tile
+  t.ntiles = tokens / (nt * 32);
+  static const bool trace_on = getenv("SSHIP_FFN_TRACE") != nullptr;
+  static unsigned long long* trace_buf = nullptr;
+  const int trace_wg = t.ntiles < 256 ? t.ntiles : 256;
+  if (trace_on) {
+    if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)256 * 8 * 12 * 8);
+    (void)hipMemsetAsync(trace_buf, 0, (size_t)256 * 8 * 12 * 8, s);
+    t.trace = trace_buf;
+  }
   if (!next) {
-    launch_ffn_nw<0, false>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    (void)launch_ffn<0, false>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    if (trace_on) ffn_trace_report(trace_buf, trace_wg, 0, s);
     return;
   }
   t.proj = token_args(*next, x, 256, nullptr, 0, d);
@@ -646,9 +772,10 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
   const int mt = next->cout / 256;  // rows per wave / 32: 768 -> 3, 512 -> 2, 256 -> 1
-  if (heads && mt == 3) launch_ffn_nw<3, true>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
-  else if (heads && mt == 2) launch_ffn_nw<2, true>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
-  else launch_ffn_nw<1, false>(nw, grid, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  if (heads && mt == 3) (void)launch_ffn<3, true>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else if (heads && mt == 2) (void)launch_ffn<2, true>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else (void)launch_ffn<1, false>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  if (trace_on) ffn_trace_report(trace_buf, trace_wg, mt, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
