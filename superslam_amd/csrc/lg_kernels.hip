@@ -336,9 +336,32 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
 //     launch on the 64-token tile that is already on chip: wave w owns NEXT_MT*32 output rows, K = 256, epilogue =
 //     the igemm epilogue of that projection (EpiHeads / plain fp16).
 constexpr int kFfnLd = 520;
+// compile-time ablation of the FFN kernel (build.py --variant -DSSHIP_FFN_ABL=n): 1 skip ffn.0 MFMAs, 2 skip LN/GELU
+// math, 4 skip ffn.3, 8 skip the fused projection's MFMAs, 16 skip input staging, 32 skip the projection epilogue,
+// 64 skip the residual update.  (Run-time flags put a branch in front of every GELU element.)
+#ifndef SSHIP_FFN_ABL
+#define SSHIP_FFN_ABL 0
+#endif
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// exact-erf GELU on two values with packed fp32 math: gelu(y) = y Phi(y) = max(y, 0) - h, h = 0.5 |y| erfc(|y| / sqrt 2),
+// erfc(|y|/sqrt 2) = p(t) exp(-y^2/2), t = 1 / (1 + 0.3275911 |y| / sqrt 2)  (Abramowitz & Stegun 7.1.26, |err| <= 1.5e-7;
+// the 0.5 is folded into the polynomial).  2 transcendentals + ~8 packed ops per value.
+__device__ __forceinline__ f2_t gelu2(f2_t y) {
+  const f2_t ay = {fabsf(y[0]), fabsf(y[1])};
+  const f2_t d = ay * 0.23164189f + 1.0f;
+  const f2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f2_t p = t * 0.5307027145f + -0.7265760135f;
+  p = p * t + 0.7107068705f;
+  p = p * t + -0.142248368f;
+  p = p * t + 0.127414796f;
+  const f2_t ex = ay * ay * -0.72134752f;
+  const f2_t e = {__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
+  const f2_t h = p * t * ay * e;
+  const f2_t pos = {fmaxf(y[0], 0.f), fmaxf(y[1], 0.f)};
+  return pos - h;
+}
 struct FfnTail {
   int ntiles;                               // token tiles of the launch (the kernel is persistent: tile = blockIdx.x + k gridDim.x)
-  int dbg;                                  // ablation (SSHIP_FFN_DBG): 1 skip ffn.0 MFMAs, 2 skip LN/GELU math, 4 skip ffn.3, 8 skip tail
   int copies0, copies3, copiesp;            // weight replicas (workgroup b reads replica b % copies)
   size_t stride0, stride3, stridep;         // halfs between replicas
   IgemmArgs proj;          // epilogue arguments of the fused projection (wpack/bias/outputs/rope/np/flags/cout/H)
@@ -362,13 +385,18 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char ffn_smem[];
   _Float16* s_xbuf = reinterpret_cast<_Float16*>(ffn_smem);                                   // [NBUF][NTOK][kFfnLd]
   float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_xbuf + (NT == 2 ? 2 : 1) * XBUF);  // [8][NTOK]
+  // ffn.0 bias, LayerNorm gamma / beta, ffn.3 bias: the same for every tile of this persistent workgroup -> LDS once
+  // (they were 28 dependent L2 round trips per lane and tile, right on the critical path between the GEMM phases)
+  float* s_par = reinterpret_cast<float*>(s_red) + 8 * NTOK;  // [b0 512 | gamma 512 | beta 512 | b3 256]
+  for (int i = threadIdx.x; i < 1792; i += 512)
+    s_par[i] = i < 512 ? b0[i] : i < 1024 ? gamma[i - 512] : i < 1536 ? beta[i - 1024] : b3[i - 1536];
   // Token-tile staging by LDS-DMA (global_load_lds_dwordx4): one instruction per token row - lanes 0..31 fetch the 32
   // 16-byte units of x[token], lanes 32..63 those of ctx[token]; the row lands lane-linear at its (padded) LDS row.
   // No staging registers, no ds_write pass, and - with two tile buffers (NT = 2) - the NEXT tile streams in while this
   // one is in its GELU / ffn.3 phases.  The DMA is invisible to hipcc's waitcnt bookkeeping: its completion is awaited
   // explicitly (vmcnt(0) where no weight prefetch is in flight), then a barrier, then the reads.
   auto stage_tile = [&](int tile, _Float16* dst, int wave, int lane) {
-    if (tail.dbg & 16) return;
+    if (SSHIP_FFN_ABL & 16) return;
     const size_t tt = (size_t)tile * NTOK;
 #pragma unroll
     for (int k = 0; k < NTOK / 8; ++k) {
@@ -401,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   asm volatile("" : "+v"(tid));  // same for the lane-dependent address arithmetic (dozens of 64-bit offsets)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, hh = lane >> 5;
   const _Float16 *w0q = w0p + zero, *w3q = w3p + zero;
-  const float *b0q = b0 + zero, *gq = gamma + zero, *beq = beta + zero, *b3q = b3 + zero;
+  const float *b0q = s_par + zero, *gq = s_par + 512 + zero, *beq = s_par + 1024 + zero, *b3q = s_par + 1536 + zero;
   IgemmArgs pj = tail.proj;
   pj.wpack += zero; pj.bias += zero;
   const float* mwq = tail.match_w + zero;
@@ -430,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     }
 #pragma unroll
     for (int grp = 0; grp < 32 / G0; ++grp) {
-      if (tail.dbg & 1) break;
+      if (SSHIP_FFN_ABL & 1) break;
       if (grp + 1 < 32 / G0) {
 #pragma unroll
         for (int i = 0; i < G0; ++i) {
@@ -498,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
-    rstd[n] = rsqrtf(t * (1.0f / 512.0f) + 1e-5f);
+    rstd[n] = __builtin_amdgcn_rsqf(t * (1.0f / 512.0f) + 1e-5f);
   }
   stamp(2);
   // every wave has passed the LayerNorm barriers, i.e. finished the previous tile: its buffer takes the next tile.
@@ -513,22 +541,27 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       const int c = wave * 64 + m * 32 + hh * 4 + g * 8;
       const float4 gv = *reinterpret_cast<const float4*>(gq + c);
       const float4 be = *reinterpret_cast<const float4*>(beq + c);
-      const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {be.x, be.y, be.z, be.w};
+      const f2_t g01 = {gv.x, gv.y}, g23 = {gv.z, gv.w}, b01 = {be.x, be.y}, b23 = {be.z, be.w};
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float y = (acc[m][n][4 * g + e] - mean[n]) * rstd[n] * gg[e] + bb[e];
-          o[e] = (tail.dbg & 2) ? y : 0.5f * y * (1.0f + fast_erf(y * 0.70710678118654752f));
-        }
-        *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o[0], o[1], o[2], o[3]);
+        const f2_t a01 = {acc[m][n][4 * g + 0], acc[m][n][4 * g + 1]}, a23 = {acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+        const f2_t o01 = (SSHIP_FFN_ABL & 2) ? a01 : gelu2((a01 - mean[n]) * rstd[n] * g01 + b01);
+        const f2_t o23 = (SSHIP_FFN_ABL & 2) ? a23 : gelu2((a23 - mean[n]) * rstd[n] * g23 + b23);
+        *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o01[0], o01[1], o23[0], o23[1]);
       }
     }
   stamp(3);
   __syncthreads();
   stamp(4);
   // ---- ffn.3 : rows [32 wave, +32) x NTOK tokens, K = 512, + residual ----
+  // the residual operand (this lane's 16 x values per N-tile) is requested before the MFMA loop: its L2 round trip
+  // used to sit between the loop and the barrier that opens the fused projection
+  h4_t xres[4][NT];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      xres[g][n] = *reinterpret_cast<const h4_t*>(x + (t0 + n * 32 + j) * 256 + wave * 32 + hh * 4 + g * 8 + zero);
   f16x_t ac2[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
@@ -541,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     for (int i = 0; i < 16; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
-      if (tail.dbg & 4) break;
+      if (SSHIP_FFN_ABL & 4) break;
       if (grp == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) a3[1][i] = *reinterpret_cast<const h8_t*>(wp + (16 + i) * 512);
@@ -568,8 +601,8 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       h4_t* px = reinterpret_cast<h4_t*>(x + (t0 + n * 32 + j) * 256 + c);
-      if (tail.dbg & 64) continue;
-      const h4_t o = *px;
+      if (SSHIP_FFN_ABL & 64) continue;
+      const h4_t o = xres[g][n];
       const h4_t xn = to_h4((float)o[0] + (ac2[n][4 * g + 0] + bv.x), (float)o[1] + (ac2[n][4 * g + 1] + bv.y),
                             (float)o[2] + (ac2[n][4 * g + 2] + bv.z), (float)o[3] + (ac2[n][4 * g + 3] + bv.w));
       *px = xn;
@@ -601,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       constexpr int VMASK = decltype(vmask_c)::value;
       // weight fragments: two groups of GT k-steps in flight in registers, pinned above the MFMAs of the previous
       // group (a plain unrolled loop made hipcc wait for every fragment right before its MFMA: 28k clocks for 96 MFMAs)
-      constexpr int GT = NT == 2 ? 4 : 2;
+      constexpr int GT = (NT == 2 && NEXT_MT < 3) ? 4 : 2;
       h8_t at[2][GT][NEXT_MT];
 #pragma unroll
       for (int i = 0; i < GT; ++i)
@@ -609,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         for (int m = 0; m < NEXT_MT; ++m) at[0][i][m] = *reinterpret_cast<const h8_t*>(wp + (i * NEXT_MT + m) * 512);
 #pragma unroll
       for (int grp = 0; grp < 16 / GT; ++grp) {
-        if (tail.dbg & 8) break;
+        if (SSHIP_FFN_ABL & 8) break;
         if (grp + 1 < 16 / GT) {
 #pragma unroll
           for (int i = 0; i < GT; ++i)
@@ -636,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         }
       }
       stamp(8);
-      if (tail.dbg & 32) return;
+      if (SSHIP_FFN_ABL & 32) return;
       if constexpr (HEADS) {
         const int NP = pj.np, nt32 = NP >> 5;
 #pragma unroll
@@ -701,7 +734,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 }
 template <int NEXT_MT, bool HEADS, int NT, typename... A>
 static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
-  constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 8 * NT * 32 * 4;
+  constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 8 * NT * 32 * 4 + 1792 * 4;
   static_assert(smem <= 163840, "LDS budget");
   auto kern = k_lg_ffn<NEXT_MT, HEADS, NT>;
   static bool attr_set = false;
@@ -747,8 +780,6 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
                    float* logsig, hipStream_t s) {
   const int tokens = d.S * d.NP;
   FfnTail t{};
-  static const int dbg = getenv("SSHIP_FFN_DBG") ? atoi(getenv("SSHIP_FFN_DBG")) : 0;
-  t.dbg = dbg;
   t.copies0 = w0.copies; t.stride0 = w0.copy_stride; t.copies3 = w3.copies; t.stride3 = w3.copy_stride;
   t.copiesp = 1; t.stridep = 0;
   const int nt = 2;  // 32-token N-tiles per workgroup tile
