@@ -200,10 +200,14 @@ static const Tensor* find_tensor(const StateDict& sd, const std::string& name, s
 // `w` is [cout][cin][ks][ks] row-major (PyTorch Conv2d / Linear); row_map/scale allow host-side row
 // permutation and folding of constant factors.
 // ------------------------------------------------------------------------------------------------
+// tile_interleave: M-tile mt of row block cb holds logical rows (mt * nblocks + cb) * 32 .. + 31 instead of
+// cb * ct + mt * 32 .. (the fused projection of the LightGlue FFN kernel: every wave then owns one 32-row tile of
+// EACH of the q / k / v segments, so all waves have the same epilogue work).  The bias stays in logical order.
 static int upload_conv(const float* w, const float* bias, int cout, int cin, int ks, int ct, ConvW& out,
                        const std::vector<int>* row_map = nullptr, const std::vector<float>* row_scale = nullptr,
-                       int copies = 1) {
+                       int copies = 1, bool tile_interleave = false) {
   const int cout_pad = (cout + ct - 1) / ct * ct, mt_n = ct / 32, nchunk = cin / 64;
+  const int nblocks = cout_pad / ct;
   std::vector<_Float16> pk((size_t)cout_pad * cin * ks * ks);
   size_t o = 0;
   for (int cb = 0; cb < cout_pad / ct; ++cb)
@@ -214,7 +218,7 @@ static int upload_conv(const float* w, const float* bias, int cout, int cin, int
             for (int mt = 0; mt < mt_n; ++mt)
               for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                  const int co = cb * ct + mt * 32 + (lane & 31);
+                  const int co = tile_interleave ? (mt * nblocks + cb) * 32 + (lane & 31) : cb * ct + mt * 32 + (lane & 31);
                   const int ci = ch * 64 + kstep * 16 + (lane >> 5) * 8 + e;
                   float v = 0.f;
                   if (co < cout) {
@@ -928,7 +932,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     {
       const Tensor* wt = find_tensor(sd, ps + "Wqkv.weight", {768, 256}, err);
       const Tensor* bs = find_tensor(sd, ps + "Wqkv.bias", {768}, err);
-      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 768, 256, 1, 96, w->qkv_t[i], &qkv_map, &qkv_scale, lg_copies()))) return bail(rc, g_err);
+      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 768, 256, 1, 96, w->qkv_t[i], &qkv_map, &qkv_scale, lg_copies(), true))) return bail(rc, g_err);
     }
     if ((rc = ffn(ps, "out_proj", w->ffn0_s[i], w->ffn3_s[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(ps + "ffn.1.weight", 512, &w->ln_g_s[i]))) return bail(rc, err);
@@ -946,7 +950,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     memcpy(bcat.data() + 256, bv->data.data(), 256 * 4);
     for (int r = 0; r < 256; ++r) scat[r] = cq_scale[r];
     if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 128, w->cqkv[i], nullptr, &scat))) return bail(rc, g_err);
-    if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 64, w->cqkv_t[i], nullptr, &scat, lg_copies()))) return bail(rc, g_err);
+    if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 64, w->cqkv_t[i], nullptr, &scat, lg_copies(), true))) return bail(rc, g_err);
     if ((rc = ffn(pc, "to_out", w->ffn0_c[i], w->ffn3_c[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(pc + "ffn.1.weight", 512, &w->ln_g_c[i]))) return bail(rc, err);
     if ((rc = vec(pc + "ffn.1.bias", 512, &w->ln_b_c[i]))) return bail(rc, err);

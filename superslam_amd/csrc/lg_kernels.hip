@@ -384,10 +384,10 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   constexpr int XBUF = NTOK * kFfnLd;  // halfs per token-tile buffer
   extern __shared__ __attribute__((aligned(16))) char ffn_smem[];
   _Float16* s_xbuf = reinterpret_cast<_Float16*>(ffn_smem);                                   // [NBUF][NTOK][kFfnLd]
-  float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_xbuf + (NT == 2 ? 2 : 1) * XBUF);  // [8][NTOK]
+  float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_xbuf + (NT == 2 ? 2 : 1) * XBUF);  // [16][NTOK]: per-wave sums, sums of squares
   // ffn.0 bias, LayerNorm gamma / beta, ffn.3 bias: the same for every tile of this persistent workgroup -> LDS once
   // (they were 28 dependent L2 round trips per lane and tile, right on the critical path between the GEMM phases)
-  float* s_par = reinterpret_cast<float*>(s_red) + 8 * NTOK;  // [b0 512 | gamma 512 | beta 512 | b3 256]
+  float* s_par = reinterpret_cast<float*>(s_red) + 16 * NTOK;  // [b0 512 | gamma 512 | beta 512 | b3 256]
   for (int i = threadIdx.x; i < 1792; i += 512)
     s_par[i] = i < 512 ? b0[i] : i < 1024 ? gamma[i - 512] : i < 1536 ? beta[i - 1024] : b3[i - 1536];
   // Token-tile staging by LDS-DMA (global_load_lds_dwordx4): one instruction per token row - lanes 0..31 fetch the 32
@@ -495,44 +495,41 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         sum[n] += (acc[m][n][4 * g + 0] + acc[m][n][4 * g + 1]) + (acc[m][n][4 * g + 2] + acc[m][n][4 * g + 3]);
       }
     }
+  // one pass: sum and sum of squares together (one barrier round instead of two; 512 fp32 terms of O(1) magnitude)
   float mean[NT], rstd[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    sum[n] += __shfl_xor(sum[n], 32, 64);
-    if (hh == 0) s_red[wave][n * 32 + j] = sum[n];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
-    mean[n] = t * (1.0f / 512.0f);
-  }
-  __syncthreads();
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     float sq = 0.f;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float dlt = acc[m][n][r] - mean[n]; sq += dlt * dlt; }
+      for (int r = 0; r < 16; ++r) sq = fmaf(acc[m][n][r], acc[m][n][r], sq);
+    sum[n] += __shfl_xor(sum[n], 32, 64);
     sq += __shfl_xor(sq, 32, 64);
-    if (hh == 0) s_red[wave][n * 32 + j] = sq;
+    if (hh == 0) { s_red[wave][n * 32 + j] = sum[n]; s_red[8 + wave][n * 32 + j] = sq; }
   }
   __syncthreads();
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    float t = 0.f;
+    float t = 0.f, q = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) t += s_red[w][n * 32 + j];
-    rstd[n] = __builtin_amdgcn_rsqf(t * (1.0f / 512.0f) + 1e-5f);
+    for (int w = 0; w < 8; ++w) { t += s_red[w][n * 32 + j]; q += s_red[8 + w][n * 32 + j]; }
+    mean[n] = t * (1.0f / 512.0f);
+    rstd[n] = __builtin_amdgcn_rsqf(fmaxf(q * (1.0f / 512.0f) - mean[n] * mean[n], 0.f) + 1e-5f);
   }
   stamp(2);
   // every wave has passed the LayerNorm barriers, i.e. finished the previous tile: its buffer takes the next tile.
   // Issued here because no weight prefetch is in flight (an older DMA would sit in front of it in the in-order vmcnt
   // queue) and the GELU math + ffn.3 that follow cover the HBM latency.
   if (NT == 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);
+  // the residual operand (this lane's 16 x values per N-tile) is requested before the GELU math: its L2 round trip
+  // used to sit between the ffn.3 loop and the barrier that opens the fused projection
+  h4_t xres[4][NT];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      xres[g][n] = *reinterpret_cast<const h4_t*>(x + (t0 + n * 32 + j) * 256 + wave * 32 + hh * 4 + g * 8 + zero);
   // every wave has passed two barriers since its last read of s_x: the tile can be overwritten with the hidden tile
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -554,14 +551,6 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   __syncthreads();
   stamp(4);
   // ---- ffn.3 : rows [32 wave, +32) x NTOK tokens, K = 512, + residual ----
-  // the residual operand (this lane's 16 x values per N-tile) is requested before the MFMA loop: its L2 round trip
-  // used to sit between the loop and the barrier that opens the fused projection
-  h4_t xres[4][NT];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-      xres[g][n] = *reinterpret_cast<const h4_t*>(x + (t0 + n * 32 + j) * 256 + wave * 32 + hh * 4 + g * 8 + zero);
   f16x_t ac2[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
@@ -626,15 +615,14 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     // D[token][channel] with lane = channel and 8 consecutive registers = the 8 keys of one PV A-fragment unit, so V^T is
     // written in fragment order with one 16-byte store per lane (the 2-byte transposing stores it replaces were ~16x
     // write-amplified and dominated the kernel's non-MFMA time).
-    const int t_seg = (pj.flags >> 4) & 0xf;
-    // which of this wave's M-tiles belong to the V segment is wave-uniform; the loop is instantiated per pattern
-    // (VMASK bit m = tile m is V) so its body stays branch-free: self Wqkv (3 tiles/wave): 000, 110 (wave 5), 111;
-    // cross [to_qk|to_v] (2 tiles/wave): 00, 11.
+    // The projection's rows are packed tile-interleaved (upload_conv): M-tile m of this wave is rows
+    // (8 m + wave) * 32 .. + 31, i.e. one tile of each 256-row segment (self: q | k | v, cross: qk | v).  Every wave
+    // has the same mix of rope / plain / transposed-V epilogues, and the V tile is always the last one.
     auto run_tail = [&](auto vmask_c) {
       constexpr int VMASK = decltype(vmask_c)::value;
       // weight fragments: two groups of GT k-steps in flight in registers, pinned above the MFMAs of the previous
       // group (a plain unrolled loop made hipcc wait for every fragment right before its MFMA: 28k clocks for 96 MFMAs)
-      constexpr int GT = (NT == 2 && NEXT_MT < 3) ? 4 : 2;
+      constexpr int GT = NT == 2 ? 4 : 2;
       h8_t at[2][GT][NEXT_MT];
 #pragma unroll
       for (int i = 0; i < GT; ++i)
@@ -674,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         const int NP = pj.np, nt32 = NP >> 5;
 #pragma unroll
         for (int m = 0; m < NEXT_MT; ++m) {
-          const int R0 = (wave * NEXT_MT + m) * 32;  // first output row of this M-tile
+          const int R0 = (HEADS ? (m * 8 + wave) : (wave * NEXT_MT + m)) * 32;  // first output row of this M-tile
           if ((VMASK >> m) & 1) {
             const int hd = (R0 >> 6) & 3, mth = (R0 >> 5) & 1;  // head, 32-channel half of the head
             const float bv = pj.bias[R0 + j];
@@ -700,16 +688,8 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         EpiF16<false, false>::template run<NEXT_MT, NT>(pj, ac3, 0, (int)(t0 >> 5), j, wave * NEXT_MT * 32, hh);
       }
     };
-    int vmask = 0;
-    if constexpr (HEADS) {
-#pragma unroll
-      for (int m = 0; m < NEXT_MT; ++m) vmask |= ((((wave * NEXT_MT + m) >> 3) == t_seg) ? 1 : 0) << m;
-    }
-    vmask = __builtin_amdgcn_readfirstlane(vmask);
-    constexpr int FULL = (1 << NEXT_MT) - 1;
-    if (vmask == 0) run_tail(std::integral_constant<int, 0>{});
-    else if (vmask == FULL) run_tail(std::integral_constant<int, FULL>{});
-    else run_tail(std::integral_constant<int, (FULL & ~1)>{});  // the only mixed pattern: tile 0 is K, the rest V
+    if constexpr (HEADS) run_tail(std::integral_constant<int, 1 << (NEXT_MT - 1)>{});
+    else run_tail(std::integral_constant<int, 0>{});
     if (tail.logsig) {  // matchability head of the last block: one wave per NTOK / 8 tokens
 #pragma unroll 1
       for (int tk = wave * (NTOK / 8); tk < (wave + 1) * (NTOK / 8); ++tk) {
@@ -734,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 }
 template <int NEXT_MT, bool HEADS, int NT, typename... A>
 static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
-  constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 8 * NT * 32 * 4 + 1792 * 4;
+  constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 16 * NT * 32 * 4 + 1792 * 4;
   static_assert(smem <= 163840, "LDS budget");
   auto kern = k_lg_ffn<NEXT_MT, HEADS, NT>;
   static bool attr_set = false;
