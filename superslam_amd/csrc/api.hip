@@ -514,11 +514,12 @@ static int sp_ensure(sship_sp* sp, int B, int H, int W) {
 // fused conv1a+conv1b layer (2.09 vs 2.19 ms) and loses on the others (their data role - 43.5 KB of HBM input per
 // tile - is longer than the MFMA role), so the default is  conv1ab -> ping-pong, the rest -> lock-step strip kernel.
 // SUPERSLAM_HIP_CONV = pp | strip forces one kernel everywhere (A/B runs).
-static int conv_mode() {  // 0 hybrid, 1 all ping-pong, 2 all strip
+// 3x3 conv kernel selection.  Default: the ping-pong kernel (conv_pp.hip) for every layer; SUPERSLAM_HIP_CONV=strip
+// runs the lock-step strip kernel instead (conv_strip.hip, kept for A/B runs: profiles/r01_pp_vs_strip.txt).
+static int conv_mode() {  // 1 ping-pong (default), 2 strip
   static const int v = [] {
     const char* e = getenv("SUPERSLAM_HIP_CONV");
-    if (!e) return 0;
-    return std::string(e) == "pp" ? 1 : (std::string(e) == "strip" ? 2 : 0);
+    return (e && std::string(e) == "strip") ? 2 : 1;
   }();
   return v;
 }

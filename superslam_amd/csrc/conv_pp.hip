@@ -16,10 +16,22 @@
 //   CIN = 64 : CT = 64 (MT = 2);   CIN = 128: CT = 32 (MT = 1), two 64-channel chunks per tile (two MFMA half-steps).
 //   FUSE1A (conv1b): the tile is produced by conv1a on the matrix cores (K = 9 -> 16) from u8 pixels that each lane
 //   prefetched into registers two half-steps earlier; no LDS patch, no extra barrier.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "igemm.h"
 #include "kernels.h"
+
+// store units (of 2 MT) the MFMA group writes itself; -1 = measured per-kernel default: none for the 64-channel layers
+// (incl. the fused conv1a+conv1b), everything for the 128-channel ones (build.py --variant -DSSHIP_PP_EPI=n to sweep)
+#ifndef SSHIP_PP_EPI
+#define SSHIP_PP_EPI -1
+#endif
+// role tracing (SSHIP_PP_TRACE=1 at run time) is compiled in only on request: it costs registers in the fused kernel
+#ifndef SSHIP_PP_TRACE_BUILD
+#define SSHIP_PP_TRACE_BUILD 0
+#endif
 
 namespace sship {
 
@@ -33,6 +45,7 @@ struct PpArgs {
   _Float16* out;
   int B, H, W, cout;
   int dbg;  // ablation (SSHIP_PP_DBG): 1 skip staging, 2 skip epilogue, 4 skip MFMA loop, 8 skip prefetch
+  unsigned long long* trace;  // SSHIP_PP_TRACE: [workgroup][group][4] clocks of half-steps 8..9: epilogue, stage, prefetch, mfma
 };
 
 constexpr int P_TH = 8, P_TW = 32, P_THH = 10, P_TWH = 34;
@@ -50,6 +63,7 @@ __device__ __forceinline__ int pp_lds(int row, int col, int unit) {
 template <int CIN, int CT, bool POOL, bool FUSE1A>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   constexpr int MT = CT / 32, NCHUNK = CIN / 64;
+  constexpr int EPI_MFMA = SSHIP_PP_EPI < 0 ? (CIN == 128 ? 2 : 0) : (SSHIP_PP_EPI > 2 * MT ? 2 * MT : SSHIP_PP_EPI);
   static_assert(NCHUNK * 9 * 4 * MT * 512 == P_W_HALFS, "weights must fill exactly 72 KiB");
   static_assert(!FUSE1A || CIN == 64, "conv1a fusion feeds a 64-channel layer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,6 +111,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
 
   // ---------------- staging (plain variant): global -> registers (prefetch) -> LDS ----------------
   uint4 rin[FUSE1A ? 1 : P_IN_IT];
+  // Edge tiles load from a clamped (always valid) address and are masked when the tile is WRITTEN to LDS one step
+  // later: selecting zero here would need the data, i.e. a vmcnt(0) in front of every one of the 11 loads (traced:
+  // 30k+ clocks for an edge tile's prefetch against ~1k for an interior one).
   auto prefetch_in = [&](int item) {
     if constexpr (!FUSE1A) {
       int b, y0, x0;
@@ -105,26 +122,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       int gtv = gt;
       asm volatile("" : "+v"(gtv));  // opaque: keeps the per-iteration geometry from being hoisted into ~50 live VGPRs
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
-      const _Float16* base = p.in + ((size_t)(b * p.H + (y0 - 1)) * p.W + (x0 - 1)) * CIN + chunk * 64;
+      if (interior) {
+        const _Float16* base = p.in + ((size_t)(b * p.H + (y0 - 1)) * p.W + (x0 - 1)) * CIN + chunk * 64;
 #pragma unroll
-      for (int i = 0; i < P_IN_IT; ++i) {
-        const int u = gtv + i * 256;
-        const int pix = u >> 3, part = u & 7;
-        const int py = pix / P_TWH, px = pix - py * P_TWH;
-        if (interior) {
+        for (int i = 0; i < P_IN_IT; ++i) {
+          const int u = gtv + i * 256;
+          const int pix = u >> 3, part = u & 7;
+          const int py = pix / P_TWH, px = pix - py * P_TWH;
           if (i < P_IN_IT - 1 || u < P_IN_UNITS) rin[i] = *reinterpret_cast<const uint4*>(base + (py * p.W + px) * CIN + part * 8);
-        } else {  // branch-free: clamped address + select (a conditional load would serialise behind vmcnt(0))
-          const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-          const bool ok = u < P_IN_UNITS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-          const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-          const uint4 v = *reinterpret_cast<const uint4*>(p.in + ((size_t)(b * p.H + cy) * p.W + cx) * CIN + chunk * 64 + part * 8);
-          rin[i] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+      } else {
+        const _Float16* img = p.in + (size_t)b * p.H * p.W * CIN + chunk * 64;
+#pragma unroll
+        for (int i = 0; i < P_IN_IT; ++i) {
+          const int u = min(gtv + i * 256, P_IN_UNITS - 1);
+          const int pix = u >> 3, part = u & 7;
+          const int py = pix / P_TWH, px = pix - py * P_TWH;
+          const int cy = min(max(y0 - 1 + py, 0), p.H - 1), cx = min(max(x0 - 1 + px, 0), p.W - 1);
+          rin[i] = *reinterpret_cast<const uint4*>(img + ((size_t)cy * p.W + cx) * CIN + part * 8);
         }
       }
     }
   };
-  auto stage_in = [&]() {
+  auto stage_in = [&](int item) {
     if constexpr (!FUSE1A) {
+      int b, y0, x0;
+      tile_coords(tile_of(item), b, y0, x0);
+      const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
       int gtv = gt;
       asm volatile("" : "+v"(gtv));
 #pragma unroll
@@ -132,7 +156,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         const int u = gtv + i * 256;
         const int pix = u >> 3, part = u & 7;
         const int py = pix / P_TWH, px = pix - py * P_TWH;
-        if (i < P_IN_IT - 1 || u < P_IN_UNITS) *reinterpret_cast<uint4*>(my_in + pp_lds(py, px, part)) = rin[i];
+        uint4 v = rin[i];
+        if (!interior) {  // zero padding outside the image (uniform branch: only edge tiles pay for the index math)
+          const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+          if (!(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)) v = make_uint4(0, 0, 0, 0);
+        }
+        if (i < P_IN_IT - 1 || u < P_IN_UNITS) *reinterpret_cast<uint4*>(my_in + pp_lds(py, px, part)) = v;
       }
     }
   };
@@ -173,17 +202,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
             rp[k][r] = v;
           }
         } else {
+          // edge tiles: one dword per patch row from a clamped position, fixed up (shift + zero fill) in stage_conv1a once
+          // the data is there - 27 clamped byte loads with selects made every edge prefetch wait for HBM nine times over
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
-            unsigned v = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const int gy = y0 - 2 + py + r, gx = x0 - 2 + px + c;
-              const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-              const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-              const unsigned bv = im[(size_t)cy * p.W + cx];
-              v |= (ok ? bv : 0u) << (8 * c);
-            }
+            const int cy = min(max(y0 - 2 + py + r, 0), p.H - 1), cx = min(max(x0 - 2 + px, 0), p.W - 4);
+            unsigned v;
+            __builtin_memcpy(&v, im + (size_t)cy * p.W + cx, 4);
             rp[k][r] = v;
           }
         }
@@ -202,10 +227,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       int b, y0, x0;
       tile_coords(tile_of(item), b, y0, x0);
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
+      const bool patch_interior = y0 >= 2 && y0 + P_TH + 2 <= p.H && x0 >= 2 && x0 + P_TW + 2 + 3 <= p.W;  // as in prefetch_u8
 #pragma unroll
       for (int k = 0; k < NT_W; ++k) {
         const int nt = gw + 4 * k;
         if (nt >= P_NT1A) continue;
+        if (!patch_interior) {  // undo the clamping of prefetch_u8: byte c of row r must be image column gx + c (0 outside)
+          const int py = c1_pypx[k] >> 16, px = c1_pypx[k] & 0xffff;
+          const int gx = x0 - 2 + px;
+          const int sh = gx - min(max(gx, 0), p.W - 4);  // < 0 at the left border, > 0 at the right one
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int gy = y0 - 2 + py + r;
+            unsigned v = rp[k][r];
+            v = sh < 0 ? (sh <= -4 ? 0u : v << (-8 * sh)) : (sh >= 4 ? 0u : v >> (8 * sh));
+            rp[k][r] = (gy >= 0 && gy < p.H) ? v : 0u;
+          }
+        }
         // taps (r, c) = byte c of dword r; cv convertTo: float(u8) * (1/255), then the engine's fp16 input
         _Float16 t[3][3];
 #pragma unroll
@@ -285,7 +323,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     }
   };
   // ---------------- epilogue: bias + ReLU (+ 2x2 max-pool) -> fp16 channels-last, 16-byte stores ----------------
-  auto epilogue = [&](int item) {
+  // units u = 2 m + g / 2 (one 16-byte store per pixel each); [u_lo, u_hi) selects which part of the tile this call writes
+  auto epilogue = [&](int item, int u_lo, int u_hi) {
     int b, y0, x0;
     tile_coords(tile_of(item), b, y0, x0);
     const int yb = y0 + gw * 2, x = x0 + j;
@@ -310,6 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int g = 0; g < 4; g += 2) {
+            if (2 * m + g / 2 < u_lo || 2 * m + g / 2 >= u_hi) continue;
             float q0[4], q1[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -336,6 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
+          if (2 * m + g / 2 < u_lo || 2 * m + g / 2 >= u_hi) continue;
           float q0[4], q1[4];
           pool4(m, g, q0);
           pool4(m, g + 1, q1);
@@ -348,20 +389,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   if (NW > 0) { if constexpr (FUSE1A) prefetch_u8(0); else prefetch_in(0); }
 #pragma unroll 1
   for (int s = -1; s <= s_end; ++s) {
+    const bool tr = SSHIP_PP_TRACE_BUILD && p.trace && (s == 8 || s == 9) && gw == 0 && lane == 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (tr) t0 = __builtin_readcyclecounter();
     if (((s + 1) & 1) == grp) {
       // ---- data-movement role: epilogue of the item whose MFMA just finished, stage the next item, prefetch ----
       const int w_done = (s - 1 - grp) >> 1;  // item whose MFMA ran in half-step s - 1
-      if (s - 1 - grp >= 0 && w_done < NW && (w_done % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w_done);
+      if (s - 1 - grp >= 0 && w_done < NW && (w_done % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w_done, EPI_MFMA, 2 * MT);
+      if (tr) t1 = __builtin_readcyclecounter();
       const int w_next = (s + 1 - grp) >> 1;  // item whose MFMA runs in half-step s + 1
       if (w_next < NW) {
-        if (!(p.dbg & 1)) { if constexpr (FUSE1A) stage_conv1a(w_next); else stage_in(); }
+        if (!(p.dbg & 1)) { if constexpr (FUSE1A) stage_conv1a(w_next); else stage_in(w_next); }
+        if (tr) t2 = __builtin_readcyclecounter();
         if (w_next + 1 < NW && !(p.dbg & 8)) { if constexpr (FUSE1A) prefetch_u8(w_next + 1); else prefetch_in(w_next + 1); }
+      }
+      if (tr) {
+        t3 = __builtin_readcyclecounter();
+        unsigned long long* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 6;
+        o[0] = t1 - t0; o[1] = t2 > t1 ? t2 - t1 : 0; o[2] = t2 ? t3 - t2 : 0;
       }
     } else {
       const int w = (s - grp) >> 1;
-      if (s - grp >= 0 && w < NW && !(p.dbg & 4)) mfma_item(w);
+      if (s - grp >= 0 && w < NW && !(p.dbg & 4)) {
+        mfma_item(w);
+        // the first EPI_MFMA store units are written by the MFMA group itself right after its loop: the data-movement
+        // half-step (epilogue + staging + prefetch) is the longer of the two roles, this group would only wait for it
+        if (EPI_MFMA > 0 && (w % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w, 0, EPI_MFMA);
+      }
+      if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 6 + 3] = __builtin_readcyclecounter() - t0;
     }
+    if (tr) t1 = __builtin_readcyclecounter();
     __syncthreads();
+    if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 6 + 4 + (((s + 1) & 1) == grp ? 0 : 1)] = __builtin_readcyclecounter() - t1;
   }
 }
 
@@ -385,7 +444,27 @@ static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;  // every workgroup should feed both of its wave groups
   if (gx < 1) gx = 1;
+  static const bool trace_on = SSHIP_PP_TRACE_BUILD && getenv("SSHIP_PP_TRACE") != nullptr;
+  static unsigned long long* tbuf = nullptr;
+  if (trace_on) {
+    if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 2 * 6 * 8);
+    (void)hipMemsetAsync(tbuf, 0, 4096 * 2 * 6 * 8, s);
+    a.trace = tbuf;
+  }
   hipLaunchKernelGGL(kern, dim3(gx, ncb), dim3(512), smem, s, a);
+  if (trace_on) {
+    std::vector<unsigned long long> h(4096 * 2 * 6);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum[6] = {0}; long cnt = 0;
+    for (int i = 0; i < gx * ncb * 2; ++i) {
+      if (!h[i * 6 + 3]) continue;
+      for (int k = 0; k < 6; ++k) sum[k] += (double)h[i * 6 + k];
+      ++cnt;
+    }
+    if (cnt) fprintf(stderr, "[pp trace cin=%d ct=%d pool=%d fuse=%d] epilogue=%.0f stage=%.0f prefetch=%.0f | mfma=%.0f | barrier wait after data=%.0f after mfma=%.0f (clk, %ld groups)\n",
+                     CIN, CT, (int)POOL, (int)FUSE1A, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, cnt);
+  }
   return hipGetLastError();
 }
 
