@@ -527,6 +527,22 @@ static hipError_t conv3(const ConvW& w, const _Float16* in, _Float16* out, int B
   return conv_mode() == 1 ? sp_conv3x3_pp(w, in, out, B, H, W, pool, s) : sp_conv3x3_strip(w, in, out, B, H, W, pool, s);
 }
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s);
+static bool desc_dense_mode() {
+  static const bool v = [] { const char* e = getenv("SUPERSLAM_HIP_DESC"); return e && std::string(e) == "dense"; }();
+  return v;
+}
+// descriptor rows of the selected keypoints of `B` images (cells / counts at the given pointers)
+static hipError_t desc_head(sship_sp* sp, int img0, int Hc, int Wc, const int* cell_h, const int* cell_w, const int* n_dev, int B,
+                            _Float16* out, size_t out_img_stride, hipStream_t s) {
+  const int mk = sp->cfg.max_keypoints;
+  if (desc_dense_mode()) {
+    launch_desc_head_gather(sp->cDb32, sp->aDa.as<_Float16>() + (size_t)img0 * Hc * Wc * 256, Hc, Wc, cell_h, cell_w, n_dev, mk, B, out,
+                            out_img_stride, s);
+    return hipGetLastError();
+  }
+  return launch_desc_head_sparse(sp->cDa, sp->cDb32, sp->a4b.as<_Float16>() + (size_t)img0 * Hc * Wc * 128, Hc, Wc, cell_h, cell_w, n_dev,
+                                 mk, B, out, out_img_stride, s);
+}
 
 // encoder + both heads up to (logits, raw descriptor grid).  utils/convert_superpoint_to_onnx.py:51-64,77,88.
 static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hipStream_t s, bool dense_desc) {
@@ -544,8 +560,9 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
   g_timer.mark("sp_encoder", s);
   SSHIP_HIP_CHECK(conv3(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, s));
   SSHIP_HIP_CHECK(sp_conv1x1_f32(sp->cPb, sp->aPa.as<_Float16>(), sp->logits.as<float>(), kLogitStride, B, Hc, Wc, s));
-  SSHIP_HIP_CHECK(conv3(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
-  // the dense convDb grid is only materialised for the dense API; extraction evaluates convDb at the selected cells
+  // the dense descriptor branch (convDa, convDb) is only materialised for the dense API; extraction evaluates both
+  // layers at the selected keypoints (k_desc_head_sparse).  SUPERSLAM_HIP_DESC=dense: dense convDa + gather (A/B runs).
+  if (dense_desc || desc_dense_mode()) SSHIP_HIP_CHECK(conv3(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
   if (dense_desc) SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
   g_timer.mark("sp_heads", s);
   return SSHIP_OK;
@@ -669,9 +686,8 @@ extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, 
   if (int rc = sp_select(sp, batch, h, w, nullptr, kp_out, n_out, s)) return rc;
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
-  launch_desc_head_gather(sp->cDb32, sp->aDa.as<_Float16>(), Hc, Wc, sp->cell_h.as<int>(), sp->cell_w.as<int>(), n_out,
-                          sp->cfg.max_keypoints, batch, static_cast<_Float16*>(desc_out), (size_t)sp->cfg.max_keypoints * 256, s);
-  SSHIP_HIP_CHECK(hipGetLastError());
+  SSHIP_HIP_CHECK(desc_head(sp, 0, Hc, Wc, sp->cell_h.as<int>(), sp->cell_w.as<int>(), n_out, batch, static_cast<_Float16*>(desc_out),
+                            (size_t)sp->cfg.max_keypoints * 256, s));
   g_timer.mark("sp_gather", s);
   return SSHIP_OK;
 }
@@ -772,10 +788,8 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
     outs[b]->n = 0; outs[b]->desc_dev = nullptr;
     outs[b]->slot = sship_pool_acquire(sp->pool);  // pool_->make(n), SuperPoint.cc:721
     if (outs[b]->slot < 0) { rc_pool = SSHIP_ERR_POOL_EXHAUSTED; continue; }
-    launch_desc_head_gather(sp->cDb32, sp->aDa.as<_Float16>() + (size_t)b * Hc * Wc * 256, Hc, Wc,
-                            sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
-                            sp->n_dev.as<int>() + b, mk, 1,
-                            static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), 0, s);
+    SSHIP_HIP_CHECK(desc_head(sp, b, Hc, Wc, sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
+                              sp->n_dev.as<int>() + b, 1, static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), 0, s));
   }
   g_timer.mark("sp_gather", s);
   SSHIP_HIP_CHECK(hipMemcpyAsync(sp->h_kp.p, sp->kp.p, (size_t)B * mk * 12, hipMemcpyDeviceToHost, s));

@@ -133,6 +133,174 @@ __global__ __launch_bounds__(512) void k_desc_head_gather(const _Float16* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Whole descriptor head at the selected keypoints: convDa (3x3, 128 -> 256, ReLU) is ALSO evaluated only where a
+// keypoint landed - its 3x3x128 input patch is gathered from the encoder output (a4b) - and feeds convDb + the two
+// normalisations above without leaving the CU.  600 keypoints of 8084 cells at KITTI size: 13x less convDa work
+// (it was the second most expensive head layer), and neither the 256-channel convDa map nor the descriptor grid is
+// written to HBM.  Arithmetic per output is the dense kernel's: same fp16 operands, same k order (64-channel chunk,
+// tap, k-step) into an fp32 accumulator, bias, ReLU, fp16.  reference: convert_superpoint_to_onnx.py:61-64,88-89.
+// A workgroup (8 waves) owns 64 keypoints of one image; wave w owns output channels [32w, 32w+32) of both layers and
+// streams its 72 KiB of convDa fragments from L2 (packed exactly as the dense conv kernels read them, ct = 32).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kDsPatchLd = 584;  // halfs per keypoint and 64-channel chunk: 9 taps x 64 + 8 (1168 B: conflict-free b128 reads)
+__global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __restrict__ a4b, int Hc, int Wc,
+                                                          const int* __restrict__ cell_h, const int* __restrict__ cell_w,
+                                                          const int* __restrict__ n_dev, int max_kp,
+                                                          const _Float16* __restrict__ wda, const float* __restrict__ bda,
+                                                          const _Float16* __restrict__ wdb, const float* __restrict__ bdb,
+                                                          _Float16* __restrict__ out, size_t out_img_stride) {
+  extern __shared__ __attribute__((aligned(16))) char ds_smem[];
+  _Float16* s_p = reinterpret_cast<_Float16*>(ds_smem);      // [64][kDsPatchLd] patch chunk
+  _Float16* s_x = s_p + 64 * kDsPatchLd;                      // [64][kDhLd] convDa output (convDb input)
+  float (*s_red)[64] = reinterpret_cast<float (*)[64]>(s_x + 64 * kDhLd);
+  int* s_cell = reinterpret_cast<int*>(s_red + 8);            // [64] (cell_h << 16 | cell_w), -1 = no keypoint
+  const int b = blockIdx.y, i0 = blockIdx.x * 64;
+  const int n = min(max(n_dev[b], 0), max_kp);
+  if (i0 >= n) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  if (tid < 64)
+    s_cell[tid] = i0 + tid < n ? (cell_h[(size_t)b * max_kp + i0 + tid] << 16) | cell_w[(size_t)b * max_kp + i0 + tid] : -1;
+  const _Float16* img = a4b + (size_t)b * Hc * Wc * 128;
+  // ---- convDa at the keypoints ----
+  f16x_t acc[2];
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nn][r] = 0.f;
+  const _Float16* wa = wda + (size_t)wave * (72 * 512) + lane * 8;  // [cb = wave][chunk][tap][kstep][lane][8]
+  h8_t fa[2][12];  // two groups of 12 fragments (one kernel row: 3 taps x 4 k-steps) in flight
+#pragma unroll
+  for (int i = 0; i < 12; ++i) fa[0][i] = *reinterpret_cast<const h8_t*>(wa + i * 512);
+  __syncthreads();  // s_cell
+#pragma unroll
+  for (int chunk = 0; chunk < 2; ++chunk) {  // unrolled: the fragment double buffer is indexed by the parity of g_lin
+    if (chunk) __syncthreads();  // every wave is done reading the previous chunk's patches
+    for (int u = tid; u < 64 * 72; u += 512) {
+      const int kp = u / 72, rem = u - kp * 72, tap = rem >> 3, part = rem & 7;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int c = s_cell[kp];
+      const int y = (c >> 16) + ky - 1, x = (c & 0xffff) + kx - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (c >= 0 && y >= 0 && y < Hc && x >= 0 && x < Wc)  // conv padding = 1: taps outside the map are zero
+        v = *reinterpret_cast<const uint4*>(img + ((size_t)y * Wc + x) * 128 + chunk * 64 + part * 8);
+      *reinterpret_cast<uint4*>(s_p + kp * kDsPatchLd + tap * 64 + part * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int grp = 0; grp < 3; ++grp) {
+      const int g_lin = chunk * 3 + grp;  // 0..5 over the whole k range; buffers alternate across the chunk boundary
+      if (g_lin + 1 < 6) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) fa[(g_lin + 1) & 1][i] = *reinterpret_cast<const h8_t*>(wa + ((g_lin + 1) * 12 + i) * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const int tap = grp * 3 + (i >> 2), ks = i & 3;
+        const h8_t b0 = *reinterpret_cast<const h8_t*>(s_p + j * kDsPatchLd + tap * 64 + ks * 16 + hh * 8);
+        const h8_t b1 = *reinterpret_cast<const h8_t*>(s_p + (32 + j) * kDsPatchLd + tap * 64 + ks * 16 + hh * 8);
+        acc[0] = mfma32(fa[g_lin & 1][i], b0, acc[0]);
+        acc[1] = mfma32(fa[g_lin & 1][i], b1, acc[1]);
+      }
+    }
+  }
+  // convDb fragments: requested now, they land while the convDa epilogue runs
+  h8_t a[16];
+  {
+    const _Float16* w = wdb + (size_t)wave * (16 * 512) + lane * 8;  // packed [cb = wave][k16][lane][8] (ct = 32)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) a[ks] = *reinterpret_cast<const h8_t*>(w + ks * 512);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 bv = *reinterpret_cast<const float4*>(bda + wave * 32 + hh * 4 + g * 8);
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+      *reinterpret_cast<h4_t*>(s_x + (nn * 32 + j) * kDhLd + wave * 32 + hh * 4 + g * 8) =
+          to_h4(fmaxf(acc[nn][4 * g] + bv.x, 0.f), fmaxf(acc[nn][4 * g + 1] + bv.y, 0.f),
+                fmaxf(acc[nn][4 * g + 2] + bv.z, 0.f), fmaxf(acc[nn][4 * g + 3] + bv.w, 0.f));
+  }
+  __syncthreads();
+  // ---- convDb + F.normalize + gather renormalisation (as k_desc_head_gather) ----
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nn][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const h8_t b0 = *reinterpret_cast<const h8_t*>(s_x + j * kDhLd + ks * 16 + hh * 8);
+    const h8_t b1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kDhLd + ks * 16 + hh * 8);
+    acc[0] = mfma32(a[ks], b0, acc[0]);
+    acc[1] = mfma32(a[ks], b1, acc[1]);
+  }
+  float v[2][16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 bv = *reinterpret_cast<const float4*>(bdb + wave * 32 + hh * 4 + g * 8);
+    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[nn][4 * g + e] = (float)(_Float16)(acc[nn][4 * g + e] + bb[e]);
+  }
+  auto row_sum_sq = [&](float (&tot)[2]) {
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      float ss = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ss += v[nn][r] * v[nn][r];
+      ss += __shfl_xor(ss, 32, 64);
+      if (hh == 0) s_red[wave][nn * 32 + j] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += s_red[w][nn * 32 + j];
+      tot[nn] = t;
+    }
+    __syncthreads();
+  };
+  float tot[2];
+  row_sum_sq(tot);
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn) {
+    const float denom = fmaxf(sqrtf(tot[nn]), 1e-12f);  // F.normalize(p=2, dim=1, eps=1e-12)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[nn][r] = (float)(_Float16)(v[nn][r] / denom);  // the fp16 dense descriptor
+  }
+  row_sum_sq(tot);
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn) {
+    const int i = i0 + nn * 32 + j;
+    if (i >= n) continue;
+    const float inv = rsqrtf(tot[nn] + 1e-12f);  // DescriptorGather.cu:46
+    _Float16* orow = out + (size_t)b * out_img_stride + (size_t)i * 256 + wave * 32 + hh * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<h4_t*>(orow + g * 8) =
+          to_h4(v[nn][4 * g] * inv, v[nn][4 * g + 1] * inv, v[nn][4 * g + 2] * inv, v[nn][4 * g + 3] * inv);
+  }
+}
+
+hipError_t launch_desc_head_sparse(const ConvW& da32, const ConvW& db32, const _Float16* a4b, int Hc, int Wc, const int* cell_h,
+                                   const int* cell_w, const int* n_dev, int max_kp, int B, _Float16* out, size_t out_img_stride,
+                                   hipStream_t s) {
+  if (da32.cin != 128 || da32.cout != 256 || da32.ct != 32 || da32.ks != 3) return hipErrorInvalidValue;
+  constexpr size_t smem = (size_t)64 * kDsPatchLd * 2 + (size_t)64 * kDhLd * 2 + 8 * 64 * 4 + 64 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_desc_head_sparse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_desc_head_sparse, dim3((max_kp + 63) / 64, B), dim3(512), smem, s, a4b, Hc, Wc, cell_h, cell_w, n_dev,
+                     max_kp, da32.w, da32.bias, db32.w, db32.bias, out, out_img_stride);
+  return hipGetLastError();
+}
+
 void launch_desc_head_gather(const ConvW& db32, const _Float16* da, int Hc, int Wc, const int* cell_h, const int* cell_w,
                              const int* n_dev, int max_kp, int B, _Float16* out, size_t out_img_stride, hipStream_t s) {
   hipLaunchKernelGGL(k_desc_head_gather, dim3((max_kp + 63) / 64, B), dim3(512), 0, s, da, Hc, Wc, cell_h, cell_w, n_dev,
