@@ -145,7 +145,11 @@ __device__ __forceinline__ float max_xor32(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = {lo half, lo half}, r[1] = {hi, hi}
   return max3f(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[1]));
 }
-template <int QT>
+// KS = waves that split the keys of one query group (flash-decoding style); the workgroup's 4 waves hold 4 / KS query
+// groups of 32 QT queries.  KS = 4 (latency mode): 32 QT queries per workgroup, 5 key tiles per wave at 640 keys.
+// KS = 2 (throughput): twice the key tiles per wave, so the per-wave prologue (Q + first K/V fragments) and the LDS merge
+// of the partials are amortised over twice as many iterations, and half as many partials are merged per query.
+template <int QT, int KS>
 __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                          const _Float16* __restrict__ vt, const int* __restrict__ lens,
                                                          int NP, int cross, _Float16* __restrict__ ctx) {
@@ -155,10 +159,13 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   float (*s_part)[4][34][64] = reinterpret_cast<float (*)[4][34][64]>(smem_attn);  // [QT][wave][32 O regs + m + l][lane]
   const int s = blockIdx.z, h = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const int q0 = blockIdx.x * 32 * QT;
+  const int qgrp = wave / KS, ksp = wave % KS;
+  const int qt0 = (blockIdx.x * (4 / KS) + qgrp) * QT;  // first 32-query tile of this wave's query group
+  const int q0 = qt0 * 32;
   const int sk = cross ? (s ^ 1) : s;
   const int nq = min(max(lens[s], 0), NP), nk = min(max(lens[sk], 0), NP);  // device-side counts are clamped to capacity
-  if (q0 >= nq) return;  // uniform for the whole workgroup
+  if ((int)blockIdx.x * (4 / KS) * QT * 32 >= nq) return;  // uniform for the whole workgroup
+  const bool active = q0 < nq && q0 < NP;  // wave-uniform: a query group past the end only takes part in the barrier
   // Q/K/V are stored in MFMA-fragment order per 32-token tile (EpiHeads): every operand load below is one
   // fully coalesced 1-KiB wave load (16 B per lane, lane-linear).
   const int nt32 = NP >> 5;
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)(blockIdx.x * QT + t) * 4 + ks) * 512 + lane * 8);
+      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)(active ? qt0 + t : 0) * 4 + ks) * 512 + lane * 8);
   float m[QT], l[QT];
   f16x_t o[QT][2];
 #pragma unroll
@@ -179,12 +186,12 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[t][0][r] = 0.f; o[t][1][r] = 0.f; }
   }
-  const int ntiles = (nk + 31) >> 5;
+  const int ntiles = active ? (nk + 31) >> 5 : 0;
   // K and V^T fragments are prefetched ONE FULL TILE ahead (loads for tile kt+4 are issued before the MFMAs and
   // softmax of tile kt), so ~1k cycles of L2 latency hide behind a whole iteration instead of a few MFMAs.
   h8_t kf[4], vf[2][2];
   {
-    const int kt0 = min(wave, nt32 - 1);
+    const int kt0 = min(ksp, nt32 - 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)kt0 * 4 + ks) * 512 + lane * 8);
 #pragma unroll
@@ -193,10 +200,10 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
       for (int mt = 0; mt < 2; ++mt)
         vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)kt0 * 2 + kk) * 2 + mt) * 512 + lane * 8);
   }
-  for (int kt = wave; kt < ntiles; kt += 4) {
+  for (int kt = ksp; kt < ntiles; kt += KS) {
     const int k0 = kt * 32;
     h8_t kn[4], vn[2][2];
-    const int ktn = min(kt + 4, nt32 - 1);  // clamped: the last prefetch re-reads a valid tile and is discarded
+    const int ktn = min(kt + KS, nt32 - 1);  // clamped: the last prefetch re-reads a valid tile and is discarded
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kn[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)ktn * 4 + ks) * 512 + lane * 8);
 #pragma unroll
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) vf[kk][mt] = vn[kk][mt];
   }
-  // ---- merge the 4 key-partials ----
+  // ---- merge the KS key-partials of every query group ----
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     l[t] += __shfl_xor(l[t], 32, 64);
@@ -266,30 +273,31 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     s_part[t][wave][33][lane] = l[t];
   }
   __syncthreads();
+  if (!active) return;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (q0 + t * 32 >= nq) break;
-    float mw[4], mt_all = -INFINITY;
+    float mw[KS], mt_all = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { mw[w] = s_part[t][w][32][lane]; mt_all = fmaxf(mt_all, mw[w]); }
-    float sc[4], lt = 0.f;
+    for (int w = 0; w < KS; ++w) { mw[w] = s_part[t][qgrp * KS + w][32][lane]; mt_all = fmaxf(mt_all, mw[w]); }
+    float sc[KS], lt = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < KS; ++w) {
       sc[w] = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - mt_all);
-      lt += s_part[t][w][33][lane] * sc[w];
+      lt += s_part[t][qgrp * KS + w][33][lane] * sc[w];
     }
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     _Float16* orow = ctx + ((size_t)s * NP + q0 + t * 32 + j) * 256 + h * 64;
-    // wave w finalises combined registers R = 8w .. 8w+7 (R = mt*16 + r): two groups of 4 consecutive channels
+    // split ksp finalises combined registers R = (32 / KS) ksp .. + 32 / KS - 1 (R = mt*16 + r): groups of 4 consecutive channels
 #pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-      const int R0 = wave * 8 + gq * 4;
+    for (int gq = 0; gq < 8 / KS; ++gq) {
+      const int R0 = ksp * (32 / KS) + gq * 4;
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += s_part[t][w][R0 + e][lane] * sc[w];
+        for (int w = 0; w < KS; ++w) acc += s_part[t][qgrp * KS + w][R0 + e][lane] * sc[w];
         v[e] = acc * inv;
       }
       const int mt = R0 >> 4, r = R0 & 15;
@@ -298,24 +306,32 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     }
   }
 }
-template <int QT>
+template <int QT, int KS>
 static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                         _Float16* ctx, hipStream_t s) {
   constexpr size_t smem = (size_t)QT * 4 * 34 * 64 * sizeof(float);
+  constexpr int QPB = 32 * QT * (4 / KS);  // queries per workgroup
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_lg_attention<QT>), dim3(d.NP / (32 * QT), 4, d.S), dim3(256), smem, s, q, k, vt, lens, d.NP, cross ? 1 : 0,
-                     ctx);
+  hipLaunchKernelGGL((k_lg_attention<QT, KS>), dim3((d.NP + QPB - 1) / QPB, 4, d.S), dim3(256), smem, s, q, k, vt, lens, d.NP,
+                     cross ? 1 : 0, ctx);
 }
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                          _Float16* ctx, hipStream_t s) {
-  // throughput batches: two query tiles per wave (half the K/V fragment traffic); a few pairs only: one tile per wave
-  // so the launch still has enough workgroups to cover the CUs (latency mode)
-  if (d.S * (d.NP / 64) * 4 >= 512) launch_attn<2>(q, k, vt, lens, d, cross, ctx, s);
-  else launch_attn<1>(q, k, vt, lens, d, cross, ctx, s);
+  // throughput batches: two query tiles per wave (half the K/V fragment traffic) and a 2-way key split; a few pairs only:
+  // one tile per wave, 4-way key split, so the launch still has enough workgroups to cover the CUs (latency mode).
+  // SUPERSLAM_HIP_ATTN_KS=4 keeps the 4-way split for throughput batches (A/B runs).
+  static const int ks_env = getenv("SUPERSLAM_HIP_ATTN_KS") ? atoi(getenv("SUPERSLAM_HIP_ATTN_KS")) : 0;
+  if (d.S * (d.NP / 64) * 4 >= 512) {
+    if (ks_env == 4) launch_attn<2, 4>(q, k, vt, lens, d, cross, ctx, s);
+    else if (ks_env == 1) launch_attn<2, 1>(q, k, vt, lens, d, cross, ctx, s);
+    else launch_attn<2, 2>(q, k, vt, lens, d, cross, ctx, s);
+  } else {
+    launch_attn<1, 4>(q, k, vt, lens, d, cross, ctx, s);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
