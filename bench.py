@@ -201,7 +201,7 @@ def main():
         # layer 0 / 11 are stand-alone reference kernels that are NOT on the extraction path (conv1a is fused into
         # conv1b's staging, convDb runs only at the selected keypoints inside k_desc_head_gather)
         for lid, name in enumerate(["conv1a_standalone_offpath", "conv1a+conv1b+pool", "conv2a", "conv2b+pool", "conv3a",
-                                    "conv3b+pool", "conv4a", "conv4b", "convPa", "convPb", "convDa", "convDb_dense_offpath"]):
+                                    "conv3b+pool", "conv4a", "conv4b", "convPa", "convPb", "convDa_dense_offpath", "convDb_dense_offpath"]):
             m2 = C.c_float(0)
             _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, lid, 2 * P, H, W, 10, C.byref(m2), None))
             layer_ms[name] = round(m2.value, 4)
@@ -217,11 +217,20 @@ def main():
             except Exception:
                 traffic = None
         alg_bytes = 2 * P * (H * W + (H // 2) * (W // 2) * 64 * 2)   # u8 image in, pooled fp16 64-ch map out
+        # what the matrix pipe sustains on THIS box under its power budget (pure register-resident MFMA stream):
+        # zero operands run at the datasheet rate, random ones about a third lower - context for `frac`
+        probe = {}
+        for name, rnd in (("zero_operands", 0), ("random_operands", 1)):
+            tf = C.c_float(0)
+            _lib.check(_lib.lib().sship_mfma_probe(rnd, C.byref(tf)))
+            probe[name] = round(tf.value, 1)
         roofline = {"kernel": "conv3x3_pp<64,64,pool,fuse1a> (conv1a+conv1b+maxpool, 36 % of the pair's FLOPs)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launch_ms": round(ms.value, 4), "flops_per_launch": 2.0 * macs.value,
-                    "algorithmic_bytes_per_launch": alg_bytes}
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "sustained_mfma_probe_tflops": probe,
+                    "frac_of_sustained_random_probe": round(ach / probe["random_operands"], 4) if probe["random_operands"] > 0 else None}
         flops_pair = 2 * sp_flops_per_image(H, W) + lg_flops_per_pair(args.max_kp)
         out = {
             "metric": "stereo pairs/sec (SPx2+LG) at 1376x376", "value": round(value, 2), "unit": "pairs/s",

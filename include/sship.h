@@ -215,6 +215,12 @@ int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
  * 11 convDb.  *macs receives the layer's multiply-accumulate count for that shape. */
 int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms, double* macs);
 
+/* Measurement aid for the roofline line: the v_mfma_f32_32x32x16_f16 rate (TFLOP/s) the device sustains from registers
+ * for ~5 ms on every CU, with zero (random_operands = 0) or random fp16 operands.  The chip clocks to its power budget,
+ * so the random-operand figure (about 1.6 PFLOP/s on MI355X) - not the 2.5 PFLOP/s datasheet peak - is what a real
+ * convolution can approach.  No reference counterpart (the reference has no measurement API). */
+int sship_mfma_probe(int random_operands, float* tflops);
+
 #ifdef __cplusplus
 }
 #endif

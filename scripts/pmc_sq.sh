@@ -2,7 +2,7 @@
 # Wave-cycle breakdown (SQ counters) of every kernel in one bench step.  Two --pmc passes (8 SQ slots per pass),
 # kernel-trace only.  usage (GPU box, repo root): scripts/pmc_sq.sh <pairs> <out.txt>
 # WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~= WAVE_CYCLES (quad-cycles); VALU_MFMA_BUSY_CYCLES is in cycles.
-P=${1:-32}
+P=${1:-64}
 OUT=${2:-gpurun_out/pmc_sq.txt}
 R=$(pwd)
 mkdir -p /tmp/pmc_sq gpurun_out

@@ -3,7 +3,7 @@
 # SEPARATE --pmc passes (TCC slots), kernel-trace only; FETCH_SIZE is doubled on gfx950 for wide coalesced reads.
 # usage (on the GPU box, from the repo root): scripts/pmc_traffic.sh <pairs>
 set -e
-P=${1:-32}
+P=${1:-64}
 R=$(pwd)
 mkdir -p /tmp/pmc_t gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -71,6 +71,7 @@ _SIGS = {
     "sship_desc_to_host": (ip, [vp, ip, ip, vp]),
     "sship_frontend_batch_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp, vp]),
     "sship_sp_bench_layer": (ip, [vp, ip, ip, ip, ip, ip, C.POINTER(fp), C.POINTER(C.c_double)]),
+    "sship_mfma_probe": (ip, [ip, C.POINTER(fp)]),
     "sship_set_profiling": (None, [ip]),
     "sship_get_stage_timings": (ip, [C.POINTER(C.c_char_p), C.POINTER(fp), ip]),
     "sship_set_log_callback": (None, [vp]),

@@ -712,6 +712,13 @@ extern "C" int sship_sp_dense(sship_sp* sp, const uint8_t* imgs, int batch, int 
   return SSHIP_OK;
 }
 
+extern "C" int sship_mfma_probe(int random_operands, float* tflops) {
+  if (!tflops) return fail(SSHIP_ERR_INVALID, "mfma_probe: null argument");
+  if (int rc = require_device()) return rc;
+  SSHIP_HIP_CHECK(mfma_probe(random_operands != 0, tflops));
+  return SSHIP_OK;
+}
+
 extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms,
                                     double* macs) {
   if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 11) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");

@@ -1,0 +1,75 @@
+// Measurement aid (sship_mfma_probe): the v_mfma_f32_32x32x16_f16 rate this device sustains from registers, with
+// zero or random operands.  MI355X clocks to its power budget: 2.3-2.4 PFLOP/s with zero operands, about 1.6 PFLOP/s
+// with random ones - the ceiling a real convolution can approach, reported next to the 2.5 PFLOP/s datasheet peak.
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace sship {
+
+__global__ __launch_bounds__(512) void k_mfma_probe(const _Float16* a, const _Float16* b, float* out, int iters) {
+  const int lane = threadIdx.x & 63;
+  h8_t fa[4], fb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    fa[i] = *reinterpret_cast<const h8_t*>(a + (i * 64 + lane) * 8);
+    fb[i] = *reinterpret_cast<const h8_t*>(b + (i * 64 + lane) * 8);
+  }
+  f16x_t acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = mfma32(fa[(u + n) & 3], fb[u & 3], acc[n]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[n][r];
+  if (s == 12345.f) out[0] = s;  // keeps the MFMA chain alive
+}
+
+hipError_t mfma_probe(bool random_operands, float* tflops) {
+  std::vector<_Float16> ha(2048), hb(2048);
+  unsigned seed = 12345u;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((int)(seed >> 8) % 2001 - 1000) * 1e-3f; };
+  for (int i = 0; i < 2048; ++i) { ha[i] = (_Float16)(random_operands ? rnd() : 0.f); hb[i] = (_Float16)(random_operands ? rnd() : 0.f); }
+  _Float16 *a = nullptr, *b = nullptr;
+  float* o = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipSuccess;
+  auto done = [&](hipError_t rc) {
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (o) (void)hipFree(o);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+  };
+  if ((e = hipMalloc(reinterpret_cast<void**>(&a), 4096)) != hipSuccess) return done(e);
+  if ((e = hipMalloc(reinterpret_cast<void**>(&b), 4096)) != hipSuccess) return done(e);
+  if ((e = hipMalloc(reinterpret_cast<void**>(&o), 4)) != hipSuccess) return done(e);
+  if ((e = hipMemcpy(a, ha.data(), 4096, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
+  if ((e = hipMemcpy(b, hb.data(), 4096, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
+  if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return done(e);
+  const int iters = 4000, nwg = 256;  // 2 waves per SIMD on every CU, ~5 ms
+  float ms = 0.f;
+  for (int rep = 0; rep < 2; ++rep) {  // the second launch is the measurement (clocks settled)
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_mfma_probe, dim3(nwg), dim3(512), 0, nullptr, a, b, o, iters);
+    (void)hipEventRecord(e1, nullptr);
+    if ((e = hipEventSynchronize(e1)) != hipSuccess) return done(e);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  *tflops = (float)((double)nwg * 8 * iters * 32.0 * 32768.0 / ((double)ms * 1e9));
+  return done(hipSuccess);
+}
+
+}  // namespace sship
