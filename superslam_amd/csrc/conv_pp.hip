@@ -273,9 +273,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
           const int base = c1_lds[k] & 0xffffff, sw = c1_lds[k] >> 24;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            h4_t o0 = to_h4(fmaxf(d0[4 * g], 0.f), fmaxf(d0[4 * g + 1], 0.f), fmaxf(d0[4 * g + 2], 0.f), fmaxf(d0[4 * g + 3], 0.f));
-            h4_t o1 = to_h4(fmaxf(d1[4 * g], 0.f), fmaxf(d1[4 * g + 1], 0.f), fmaxf(d1[4 * g + 2], 0.f), fmaxf(d1[4 * g + 3], 0.f));
-            if (!inside) { o0 = to_h4(0.f, 0.f, 0.f, 0.f); o1 = o0; }
+            // ReLU after the fp16 rounding, two values per instruction (v_pk_max_f16): rounding is monotone and keeps the
+            // sign, so relu(fp16(x)) == fp16(relu(x))
+            const h4_t z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            h4_t o0 = __builtin_elementwise_max(to_h4(d0[4 * g], d0[4 * g + 1], d0[4 * g + 2], d0[4 * g + 3]), z4);
+            h4_t o1 = __builtin_elementwise_max(to_h4(d1[4 * g], d1[4 * g + 1], d1[4 * g + 2], d1[4 * g + 3]), z4);
+            if (!interior && !inside) { o0 = z4; o1 = z4; }  // `interior` is uniform: inner tiles skip the selects
             const int u0 = (g ^ sw) << 3;  // channels 4 hh + 8 g .. (+3): unit g; M-tile 1: unit 4 + g
             *reinterpret_cast<h4_t*>(my_in + base + u0) = o0;
             *reinterpret_cast<h4_t*>(my_in + base + (u0 ^ 32)) = o1;
