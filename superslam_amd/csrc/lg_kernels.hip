@@ -149,10 +149,17 @@ __device__ __forceinline__ float max_xor32(float x) {
 // groups of 32 QT queries.  KS = 4 (latency mode): 32 QT queries per workgroup, 5 key tiles per wave at 640 keys.
 // KS = 2 (throughput): twice the key tiles per wave, so the per-wave prologue (Q + first K/V fragments) and the LDS merge
 // of the partials are amortised over twice as many iterations, and half as many partials are merged per query.
+// developer aid: -DSSHIP_ATTN_TRACE_BUILD=1 + SSHIP_ATTN_TRACE=1 prints mean clocks of prologue / key loop / merge per wave
+#ifndef SSHIP_ATTN_TRACE_BUILD
+#define SSHIP_ATTN_TRACE_BUILD 0
+#endif
 template <int QT, int KS>
 __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                          const _Float16* __restrict__ vt, const int* __restrict__ lens,
-                                                         int NP, int cross, _Float16* __restrict__ ctx) {
+                                                         int NP, int cross, _Float16* __restrict__ ctx,
+                                                         unsigned long long* __restrict__ trace) {
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+  if (SSHIP_ATTN_TRACE_BUILD && trace) tr0 = __builtin_readcyclecounter();
   // One workgroup = 32*QT queries of one (sequence, head); its 4 waves split the KEYS (tile kt -> wave kt & 3,
   // flash-decoding style) and merge their (m, l, O) partials through LDS.
   extern __shared__ __attribute__((aligned(16))) char smem_attn[];
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
       for (int mt = 0; mt < 2; ++mt)
         vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)kt0 * 2 + kk) * 2 + mt) * 512 + lane * 8);
   }
+  if (SSHIP_ATTN_TRACE_BUILD && trace) tr1 = __builtin_readcyclecounter();
   for (int kt = ksp; kt < ntiles; kt += KS) {
     const int k0 = kt * 32;
     h8_t kn[4], vn[2][2];
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) vf[kk][mt] = vn[kk][mt];
   }
+  if (SSHIP_ATTN_TRACE_BUILD && trace) tr2 = __builtin_readcyclecounter();
   // ---- merge the KS key-partials of every query group ----
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -305,6 +314,10 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
       *reinterpret_cast<h4_t*>(orow + d) = to_h4(v[0], v[1], v[2], v[3]);
     }
   }
+  if (SSHIP_ATTN_TRACE_BUILD && trace && lane == 0) {
+    unsigned long long* o = trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+    o[0] = tr1 - tr0; o[1] = tr2 - tr1; o[2] = __builtin_readcyclecounter() - tr2; o[3] = 1;
+  }
 }
 template <int QT, int KS>
 static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
@@ -316,8 +329,23 @@ static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
+  unsigned long long* tbuf = nullptr;
+  const size_t nwg = (size_t)((d.NP + QPB - 1) / QPB) * 4 * d.S;
+  static const bool trace_on = SSHIP_ATTN_TRACE_BUILD && getenv("SSHIP_ATTN_TRACE") != nullptr;
+  if (trace_on) { (void)hipMalloc(&tbuf, nwg * 16 * 8); (void)hipMemsetAsync(tbuf, 0, nwg * 16 * 8, s); }
   hipLaunchKernelGGL((k_lg_attention<QT, KS>), dim3((d.NP + QPB - 1) / QPB, 4, d.S), dim3(256), smem, s, q, k, vt, lens, d.NP,
-                     cross ? 1 : 0, ctx);
+                     cross ? 1 : 0, ctx, tbuf);
+  if (trace_on) {
+    std::vector<unsigned long long> h(nwg * 16);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum[3] = {0, 0, 0}; long cnt = 0;
+    for (size_t w = 0; w < nwg * 4; ++w)
+      if (h[w * 4 + 3]) { for (int i = 0; i < 3; ++i) sum[i] += (double)h[w * 4 + i]; ++cnt; }
+    if (cnt) fprintf(stderr, "[attn trace QT=%d KS=%d cross=%d] prologue=%.0f key loop=%.0f merge=%.0f clk (%ld waves, %zu workgroups)\n", QT, KS,
+                     (int)cross, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, cnt, nwg);
+    (void)hipFree(tbuf);
+  }
 }
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                          _Float16* ctx, hipStream_t s) {
