@@ -443,7 +443,7 @@ static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
   }
   const int ncb = a.cout / CT;
   const int ntiles = a.B * ((a.W + P_TW - 1) / P_TW) * ((a.H + P_TH - 1) / P_TH);
-  int gx = 256 / ncb;  // one persistent workgroup per CU
+  int gx = cu_count() / ncb;  // one persistent workgroup per CU
   if (gx < 1) gx = 1;
   if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;  // every workgroup should feed both of its wave groups
   if (gx < 1) gx = 1;

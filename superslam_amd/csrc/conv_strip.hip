@@ -347,7 +347,7 @@ static hipError_t launch_strip(const StripArgs& a_in, hipStream_t s) {
   }
   const int ncb = a.cout / CT;
   const int ntiles = a.B * ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH);
-  int gx = 256 / ncb;  // one persistent workgroup per CU (the 160 KiB LDS footprint admits exactly one)
+  int gx = cu_count() / ncb;  // one persistent workgroup per CU (the 160 KiB LDS footprint admits exactly one)
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   hipLaunchKernelGGL(kern, dim3(gx, ncb), dim3(512), smem, s, a);

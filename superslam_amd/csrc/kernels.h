@@ -69,6 +69,9 @@ hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int 
 hipError_t sp_conv1ab_pp(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img, _Float16* out,
                          int B, int H, int W, hipStream_t s);
 hipError_t sp_conv1x1_f16(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s);
+// compute units of the current device (cached; persistent kernels launch one workgroup per CU). probe.hip
+int cu_count();
+
 // probe.hip
 hipError_t mfma_probe(bool random_operands, float* tflops);
 

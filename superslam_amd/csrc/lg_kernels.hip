@@ -353,7 +353,7 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
   // one tile per wave, 4-way key split, so the launch still has enough workgroups to cover the CUs (latency mode).
   // SUPERSLAM_HIP_ATTN_KS=4 keeps the 4-way split for throughput batches (A/B runs).
   static const int ks_env = getenv("SUPERSLAM_HIP_ATTN_KS") ? atoi(getenv("SUPERSLAM_HIP_ATTN_KS")) : 0;
-  if (d.S * (d.NP / 64) * 4 >= 512) {
+  if (d.S * (d.NP / 64) * 4 >= 2 * cu_count()) {
     if (ks_env == 4) launch_attn<2, 4>(q, k, vt, lens, d, cross, ctx, s);
     else if (ks_env == 1) launch_attn<2, 1>(q, k, vt, lens, d, cross, ctx, s);
     else launch_attn<2, 2>(q, k, vt, lens, d, cross, ctx, s);
@@ -768,7 +768,7 @@ static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
     attr_set = true;
   }
   const int ntiles = tokens / (NT * 32);
-  hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), smem, s, args...);  // one persistent workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(ntiles < cu_count() ? ntiles : cu_count()), dim3(512), smem, s, args...);  // one persistent workgroup per CU
   return hipGetLastError();
 }
 // SSHIP_FFN_TRACE=1 (developer aid): mean shader-clock duration of every phase of a workgroup's second tile.
@@ -810,10 +810,10 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.ntiles = tokens / (nt * 32);
   static const bool trace_on = getenv("SSHIP_FFN_TRACE") != nullptr;
   static unsigned long long* trace_buf = nullptr;
-  const int trace_wg = t.ntiles < 256 ? t.ntiles : 256;
+  const int trace_wg = t.ntiles < cu_count() ? t.ntiles : cu_count();
   if (trace_on) {
-    if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)256 * 8 * 12 * 8);
-    (void)hipMemsetAsync(trace_buf, 0, (size_t)256 * 8 * 12 * 8, s);
+    if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)cu_count() * 8 * 12 * 8);
+    (void)hipMemsetAsync(trace_buf, 0, (size_t)cu_count() * 8 * 12 * 8, s);
     t.trace = trace_buf;
   }
   if (!next) {

@@ -9,6 +9,15 @@
 
 namespace sship {
 
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
 __global__ __launch_bounds__(512) void k_mfma_probe(const _Float16* a, const _Float16* b, float* out, int iters) {
   const int lane = threadIdx.x & 63;
   h8_t fa[4], fb[4];
@@ -59,7 +68,7 @@ hipError_t mfma_probe(bool random_operands, float* tflops) {
   if ((e = hipMemcpy(a, ha.data(), 4096, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
   if ((e = hipMemcpy(b, hb.data(), 4096, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
   if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return done(e);
-  const int iters = 4000, nwg = 256;  // 2 waves per SIMD on every CU, ~5 ms
+  const int iters = 4000, nwg = cu_count();  // 2 waves per SIMD on every CU, ~5 ms
   float ms = 0.f;
   for (int rep = 0; rep < 2; ++rep) {  // the second launch is the measurement (clocks settled)
     (void)hipEventRecord(e0, nullptr);
