@@ -510,10 +510,6 @@ static int sp_ensure(sship_sp* sp, int B, int H, int W) {
   return SSHIP_OK;
 }
 
-// 3x3 conv dispatch.  Measured at P = 32 (profiles/r01_pp_vs_strip.txt): the ping-pong kernel (conv_pp.hip) wins on the
-// fused conv1a+conv1b layer (2.09 vs 2.19 ms) and loses on the others (their data role - 43.5 KB of HBM input per
-// tile - is longer than the MFMA role), so the default is  conv1ab -> ping-pong, the rest -> lock-step strip kernel.
-// SUPERSLAM_HIP_CONV = pp | strip forces one kernel everywhere (A/B runs).
 // 3x3 conv kernel selection.  Default: the ping-pong kernel (conv_pp.hip) for every layer; SUPERSLAM_HIP_CONV=strip
 // runs the lock-step strip kernel instead (conv_strip.hip, kept for A/B runs: profiles/r01_pp_vs_strip.txt).
 static int conv_mode() {  // 1 ping-pong (default), 2 strip
@@ -548,7 +544,7 @@ static hipError_t desc_head(sship_sp* sp, int img0, int Hc, int Wc, const int* c
 static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hipStream_t s, bool dense_desc) {
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
-  // conv1a is evaluated inside conv1b's tile staging (conv_strip.hip): the 64-channel full-resolution activation
+  // conv1a is evaluated inside conv1b's tile staging (conv_pp.hip): the 64-channel full-resolution activation
   // never exists in HBM.
   SSHIP_HIP_CHECK(conv1ab(sp, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
   SSHIP_HIP_CHECK(conv3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));

@@ -1,4 +1,7 @@
 // Persistent-strip 3x3 convolution for SuperPoint's encoder / head convs (utils/convert_superpoint_to_onnx.py:38-49).
+// NOT the default any more: the ping-pong kernel (conv_pp.hip) beats it on every layer since its border-tile prefetch
+// was fixed (profiles/r01_pp_vs_strip.txt).  Kept behind SUPERSLAM_HIP_CONV=strip as the A/B reference and covered by
+// tests/test_gpu_alt_paths.py.
 //
 // Why a second conv kernel: the generic igemm kernel spends ~7.5 VALU instructions per MFMA on per-tile prologue /
 // epilogue work (rocprofv3 PMC, profiles/r01_v2_pmc_conv1b.txt: MFMA busy 24 %, no LDS conflicts, 46 % of wave
