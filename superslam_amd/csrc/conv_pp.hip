@@ -228,10 +228,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       tile_coords(tile_of(item), b, y0, x0);
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
       const bool patch_interior = y0 >= 2 && y0 + P_TH + 2 <= p.H && x0 >= 2 && x0 + P_TW + 2 + 3 <= p.W;  // as in prefetch_u8
+      // three passes over this wave's (up to) 3 N-tiles so the six conv1a MFMAs issue back to back and their latency
+      // (they queue behind the other group's MFMA stream on the same SIMD) overlaps instead of adding up
+      h8_t bf[NT_W];
 #pragma unroll
       for (int k = 0; k < NT_W; ++k) {
-        const int nt = gw + 4 * k;
-        if (nt >= P_NT1A) continue;
         if (!patch_interior) {  // undo the clamping of prefetch_u8: byte c of row r must be image column gx + c (0 outside)
           const int py = c1_pypx[k] >> 16, px = c1_pypx[k] & 0xffff;
           const int gx = x0 - 2 + px;
@@ -250,20 +251,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c) t[r][c] = (_Float16)((float)((rp[k][r] >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
-        h8_t bf;  // lanes hh = 0: taps 0..7; lanes hh = 1: tap 8, the two bias slots (1.0, 1.0) and zero padding
-        bf[0] = hh ? t[2][2] : t[0][0];
-        bf[1] = hh ? (_Float16)1.f : t[0][1];
-        bf[2] = hh ? (_Float16)1.f : t[0][2];
-        bf[3] = hh ? (_Float16)0.f : t[1][0];
-        bf[4] = hh ? (_Float16)0.f : t[1][1];
-        bf[5] = hh ? (_Float16)0.f : t[1][2];
-        bf[6] = hh ? (_Float16)0.f : t[2][0];
-        bf[7] = hh ? (_Float16)0.f : t[2][1];
-        f16x_t d0, d1;
+        // lanes hh = 0: taps 0..7; lanes hh = 1: tap 8, the two bias slots (1.0, 1.0) and zero padding
+        bf[k][0] = hh ? t[2][2] : t[0][0];
+        bf[k][1] = hh ? (_Float16)1.f : t[0][1];
+        bf[k][2] = hh ? (_Float16)1.f : t[0][2];
+        bf[k][3] = hh ? (_Float16)0.f : t[1][0];
+        bf[k][4] = hh ? (_Float16)0.f : t[1][1];
+        bf[k][5] = hh ? (_Float16)0.f : t[1][2];
+        bf[k][6] = hh ? (_Float16)0.f : t[2][0];
+        bf[k][7] = hh ? (_Float16)0.f : t[2][1];
+      }
+      f16x_t d0[NT_W], d1[NT_W];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-        d0 = mfma32(a1a0, bf, d0);
-        d1 = mfma32(a1a1, bf, d1);
+      for (int k = 0; k < NT_W; ++k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d0[k][r] = 0.f; d1[k][r] = 0.f; }
+        if (gw + 4 * k >= P_NT1A) continue;  // wave-uniform
+        d0[k] = mfma32(a1a0, bf[k], d0[k]);
+        d1[k] = mfma32(a1a1, bf[k], d1[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < NT_W; ++k) {
+        if (gw + 4 * k >= P_NT1A) continue;
         if ((gw + 4 * k) * 32 + j < P_THH * P_TWH) {
           bool inside = true;
           if (!interior) {  // conv1b's zero padding is on conv1a's OUTPUT: only edge tiles have outside halo pixels
@@ -276,8 +285,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
             // ReLU after the fp16 rounding, two values per instruction (v_pk_max_f16): rounding is monotone and keeps the
             // sign, so relu(fp16(x)) == fp16(relu(x))
             const h4_t z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            h4_t o0 = __builtin_elementwise_max(to_h4(d0[4 * g], d0[4 * g + 1], d0[4 * g + 2], d0[4 * g + 3]), z4);
-            h4_t o1 = __builtin_elementwise_max(to_h4(d1[4 * g], d1[4 * g + 1], d1[4 * g + 2], d1[4 * g + 3]), z4);
+            h4_t o0 = __builtin_elementwise_max(to_h4(d0[k][4 * g], d0[k][4 * g + 1], d0[k][4 * g + 2], d0[k][4 * g + 3]), z4);
+            h4_t o1 = __builtin_elementwise_max(to_h4(d1[k][4 * g], d1[k][4 * g + 1], d1[k][4 * g + 2], d1[k][4 * g + 3]), z4);
             if (!interior && !inside) { o0 = z4; o1 = z4; }  // `interior` is uniform: inner tiles skip the selects
             const int u0 = (g ^ sw) << 3;  // channels 4 hh + 8 g .. (+3): unit g; M-tile 1: unit 4 + g
             *reinterpret_cast<h4_t*>(my_in + base + u0) = o0;
