@@ -95,175 +95,226 @@ __device__ __forceinline__ void window9x4(const float (&v)[12], float (&o)[4]) {
 
 // RT = 4: the exporter's radius, register-window separable max with 16-byte LDS reads (the dynamic-radius loops
 // were LDS-latency-bound: ~20 us per workgroup).  RT = -1: any radius <= 8 (sship_nms stage API).
+//
+// The workgroup is persistent over tiles, and the two long latencies of a tile are taken off its critical path (phase
+// trace: HBM load 4.6k of 15.4k clocks, slot reservation 5.4k):
+//   * the logits of the NEXT tile are requested into registers (17 per lane) before the LDS phases of this one;
+//   * the global atomic that reserves the tile's slots in the per-image candidate list is issued and NOT waited for:
+//     the tile's candidates are parked in a small LDS list and written out one tile later, when the ticket has long
+//     returned (tiles with more than NMS_PEND candidates - constant plateaus - take the synchronous path).
+constexpr int NMS_PEND = 256;
+
 template <int LOADER, int RT>
 __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
   // s_s: scores incl. halo [48][84]; s_r: row maxima [48][64]; the candidate list aliases both once they are dead
   __shared__ __attribute__((aligned(16))) float s_buf[NLH * NLS + NLH * NT_W];
+  __shared__ unsigned long long s_pend[NMS_PEND];
   __shared__ int s_cnt, s_base;
   float* s_s = s_buf;
   float* s_r = s_buf + NLH * NLS;
   unsigned long long* s_c = reinterpret_cast<unsigned long long*>(s_buf);
   static_assert(sizeof(s_buf) >= NT_H * NT_W * 8, "candidate list must fit the aliased buffers");
   const int tiles_x = (a.W + NT_W - 1) / NT_W, tiles_y = (a.H + NT_H - 1) / NT_H;
-  int t = blockIdx.x;
-  const int tx = t % tiles_x; t /= tiles_x;
-  const int ty = t % tiles_y;
-  const int b = t / tiles_y;
-  const int x0 = tx * NT_W - NHALO, y0 = ty * NT_H - NHALO;  // tile origin incl. halo (multiple of 8)
+  const int ntiles = a.B * tiles_x * tiles_y;
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) s_cnt = 0;
-  if constexpr (LOADER == 0) {
-    const int Hc = a.H >> 3, Wc = a.W >> 3;
-    const int cy0 = y0 >> 3, cx0 = x0 >> 3;  // may be -1
-    // 60 cells (6 x 10 incl. the halo ring) x 4 lanes: each lane owns 16 of the 64 position channels (= 2 rows of
-    // the cell's 8 x 8 block), the group of 4 shares max / sum through two DPP exchanges.
-    constexpr int NCELL = (NLH / 8) * (NLW / 8);
-    if (tid < NCELL * 4) {
-      const int cell = tid >> 2, qd = tid & 3;
-      const int cyl = cell / (NLW / 8), cxl = cell % (NLW / 8);
-      const int cy = cy0 + cyl, cx = cx0 + cxl;
-      float v[16];
-      float d = 0.f;
-      const bool in = cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
-      if (in) {
-        const float* lp = a.logits + ((size_t)(b * Hc + cy) * Wc + cx) * a.ls;
+  // 60 cells (6 x 10 incl. the halo ring) x 4 lanes: each lane owns 16 of the 64 position channels (= 2 rows of
+  // the cell's 8 x 8 block), the group of 4 shares max / sum through two DPP exchanges.
+  constexpr int NCELL = (NLH / 8) * (NLW / 8);
+  const int cell = tid >> 2, qd = tid & 3;
+  const int cyl = cell / (NLW / 8), cxl = cell % (NLW / 8);
+  float4 pv[4];
+  float pd = 0.f;
+  bool pin = false;
+  auto fetch = [&](int tt) {
+    if constexpr (LOADER == 0) {
+      const int Hc = a.H >> 3, Wc = a.W >> 3;
+      int q = tt;
+      const int ftx = q % tiles_x; q /= tiles_x;
+      const int fty = q % tiles_y;
+      const int fb = q / tiles_y;
+      const int cy = ((fty * NT_H - NHALO) >> 3) + cyl, cx = ((ftx * NT_W - NHALO) >> 3) + cxl;  // may be -1
+      pin = tid < NCELL * 4 && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+      const int ccy = min(max(cy, 0), Hc - 1), ccx = min(max(cx, 0), Wc - 1);  // clamped: branch-free loads
+      const float* lp = a.logits + ((size_t)(fb * Hc + ccy) * Wc + ccx) * a.ls;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pv[i] = *reinterpret_cast<const float4*>(lp + qd * 16 + i * 4);
+      pd = lp[64];
+    }
+  };
+  int pend_n = 0, pend_b = 0;  // parked candidates of the previous tile (workgroup-uniform)
+  int ticket = 0;              // thread 0: first slot reserved for them (return value of the in-flight atomic)
+  auto flush_pending = [&]() {  // call after a barrier that follows `s_base = ticket`
+    if (pend_n) {
+      const int base = s_base;
+      for (int i = tid; i < pend_n; i += 256)
+        if (base + i < a.cap) a.cand[(size_t)pend_b * a.cap + base + i] = s_pend[i];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * NT_W - NHALO, y0 = ty * NT_H - NHALO;  // tile origin incl. halo (multiple of 8)
+    if (tid == 0) {
+      s_cnt = 0;
+      if (pend_n) s_base = ticket;  // the only wait for the reservation, a whole tile after it was issued
+    }
+    if constexpr (LOADER == 0) {
+      if (tid < NCELL * 4) {
+        float v[16];
+        const bool in = pin;
+        const float d = in ? pd : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float4 t4 = *reinterpret_cast<const float4*>(lp + qd * 16 + i * 4);
-          v[4 * i] = t4.x; v[4 * i + 1] = t4.y; v[4 * i + 2] = t4.z; v[4 * i + 3] = t4.w;
+          v[4 * i] = in ? pv[i].x : 0.f; v[4 * i + 1] = in ? pv[i].y : 0.f;
+          v[4 * i + 2] = in ? pv[i].z : 0.f; v[4 * i + 3] = in ? pv[i].w : 0.f;
         }
-        d = lp[64];
-      } else {
+        float m = d;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = 0.f;
-      }
-      float m = d;
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, v[i]);
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m = fmaxf(m, v[i]);
-      m = fmaxf(m, __shfl_xor(m, 1, 64));
-      m = fmaxf(m, __shfl_xor(m, 2, 64));
-      float sum = 0.f;
+        for (int i = 0; i < 16; ++i) { v[i] = __expf(v[i] - m); sum += v[i]; }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __expf(d - m);
+        const float inv = 1.0f / sum;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { v[i] = __expf(v[i] - m); sum += v[i]; }
-      sum += __shfl_xor(sum, 1, 64);
-      sum += __shfl_xor(sum, 2, 64);
-      sum += __expf(d - m);
-      const float inv = 1.0f / sum;
+        for (int r = 0; r < 2; ++r) {
+          float* dst = s_s + (cyl * 8 + qd * 2 + r) * NLS + cxl * 8;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        float* dst = s_s + (cyl * 8 + qd * 2 + r) * NLS + cxl * 8;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float4 o;
-          o.x = in ? v[r * 8 + h * 4 + 0] * inv : -INFINITY;
-          o.y = in ? v[r * 8 + h * 4 + 1] * inv : -INFINITY;
-          o.z = in ? v[r * 8 + h * 4 + 2] * inv : -INFINITY;
-          o.w = in ? v[r * 8 + h * 4 + 3] * inv : -INFINITY;
-          *reinterpret_cast<float4*>(dst + h * 4) = o;
+          for (int h = 0; h < 2; ++h) {
+            float4 o;
+            o.x = in ? v[r * 8 + h * 4 + 0] * inv : -INFINITY;
+            o.y = in ? v[r * 8 + h * 4 + 1] * inv : -INFINITY;
+            o.z = in ? v[r * 8 + h * 4 + 2] * inv : -INFINITY;
+            o.w = in ? v[r * 8 + h * 4 + 3] * inv : -INFINITY;
+            *reinterpret_cast<float4*>(dst + h * 4) = o;
+          }
         }
       }
-    }
-  } else {
-    for (int i = tid; i < NLH * NLW; i += 256) {
-      const int ly = i / NLW, lx = i % NLW;
-      const int gy = y0 + ly, gx = x0 + lx;
-      float sc = -INFINITY;
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) sc = a.scores_in[((size_t)b * a.H + gy) * a.W + gx];
-      s_s[ly * NLS + lx] = sc;
-    }
-  }
-  __syncthreads();
-  // ---- row maxima over [x-R, x+R] for the 64 interior columns of all 48 rows
-  if constexpr (RT == 4) {
-    for (int it = tid; it < NLH * (NT_W / 4); it += 256) {
-      const int row = it >> 4, seg = it & 15;
-      const float* p = s_s + row * NLS + NHALO - 4 + 4 * seg;
-      float v[12], o[4];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const float4 t4 = *reinterpret_cast<const float4*>(p + 4 * q);
-        v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+      if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // lands while this tile goes through its LDS phases
+    } else {
+      for (int i = tid; i < NLH * NLW; i += 256) {
+        const int ly = i / NLW, lx = i % NLW;
+        const int gy = y0 + ly, gx = x0 + lx;
+        float sc = -INFINITY;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) sc = a.scores_in[((size_t)b * a.H + gy) * a.W + gx];
+        s_s[ly * NLS + lx] = sc;
       }
-      window9x4(v, o);
-      *reinterpret_cast<float4*>(s_r + row * NT_W + 4 * seg) = make_float4(o[0], o[1], o[2], o[3]);
     }
-  } else {
-    const int R = a.radius;
-    for (int i = tid; i < NLH * NT_W; i += 256) {
-      const int ly = i / NT_W, lx = (i % NT_W) + NHALO;
-      float m = -INFINITY;
-      for (int d = -R; d <= R; ++d) m = fmaxf(m, s_s[ly * NLS + lx + d]);
-      s_r[ly * NT_W + (lx - NHALO)] = m;
-    }
-  }
-  __syncthreads();
-  // ---- column maxima, survival test; every thread owns NMS_SLOTS pixels whose verdicts stay in registers
-  float sc[NMS_SLOTS];
-  unsigned keep = 0;
-  unsigned pix[NMS_SLOTS];
-  auto verdict = [&](int slot, int iy, int ix, float s, float m) {
-    const int gy = y0 + NHALO + iy, gx = x0 + NHALO + ix;
-    sc[slot] = s;
-    pix[slot] = (unsigned)(gy * a.W + gx);
-    if (gy >= a.H || gx >= a.W) return;
-    const bool is_max = (RT == 4) ? (s == m) : (a.radius <= 0 || s == m);
-    const size_t o = ((size_t)b * a.H + gy) * a.W + gx;
-    if (a.scores_raw_out) a.scores_raw_out[o] = s;
-    if (a.scores_out) a.scores_out[o] = is_max ? s : 0.0f;
-    if (a.cand && is_max && s >= a.thr_f && gy >= a.border && gy < a.H - a.border && gx >= a.border &&
-        gx < a.W - a.border)
-      keep |= 1u << slot;
-  };
-  if constexpr (RT == 4) {
-#pragma unroll
-    for (int k = 0; k < NMS_SLOTS / 4; ++k) {
-      const int it = tid + k * 256;
-      const int ix = it & 63, rg = it >> 6;  // 4 consecutive interior rows 4*rg .. 4*rg+3 of column ix
-      float v[12], o[4];
-#pragma unroll
-      for (int q = 0; q < 12; ++q) v[q] = s_r[(4 * rg + NHALO - 4 + q) * NT_W + ix];
-      window9x4(v, o);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        verdict(k * 4 + q, 4 * rg + q, ix, s_s[(4 * rg + q + NHALO) * NLS + ix + NHALO], o[q]);
-    }
-  } else {
-    const int R = a.radius;
-#pragma unroll
-    for (int k = 0; k < NMS_SLOTS; ++k) {
-      const int i = tid + k * 256;
-      const int iy = i / NT_W, ix = i % NT_W;
-      float m = -INFINITY;
-      for (int d = -R; d <= R; ++d) m = fmaxf(m, s_r[(iy + NHALO + d) * NT_W + ix]);
-      verdict(k, iy, ix, s_s[(iy + NHALO) * NLS + ix + NHALO], m);
-    }
-  }
-  if (a.cand) {
-    __syncthreads();  // s_s / s_r are dead: the candidate list takes their place
-    // workgroup-local compaction: one LDS atomic per wave, ONE global atomic per tile (per-candidate global atomics
-    // on the per-image counter serialise in L2)
-    const int mine = __popc(keep);
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    const int total = __shfl(incl, 63, 64);
-    int wbase = 0;
-    if (lane == 63 && total) wbase = atomicAdd(&s_cnt, total);
-    wbase = __shfl(wbase, 63, 64);
-    int pos = wbase + incl - mine;
-#pragma unroll
-    for (int k = 0; k < NMS_SLOTS; ++k)
-      if (keep & (1u << k)) s_c[pos++] = ((unsigned long long)__float_as_uint(sc[k]) << 32) | pix[k];
     __syncthreads();
-    const int n = s_cnt;
-    if (tid == 0) s_base = n ? atomicAdd(&a.cand_count[b], n) : 0;
+    flush_pending();  // previous tile's candidates -> global (s_pend is rewritten only after the next two barriers)
+    // ---- row maxima over [x-R, x+R] for the 64 interior columns of all 48 rows
+    if constexpr (RT == 4) {
+      for (int it = tid; it < NLH * (NT_W / 4); it += 256) {
+        const int row = it >> 4, seg = it & 15;
+        const float* p = s_s + row * NLS + NHALO - 4 + 4 * seg;
+        float v[12], o[4];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const float4 t4 = *reinterpret_cast<const float4*>(p + 4 * q);
+          v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+        }
+        window9x4(v, o);
+        *reinterpret_cast<float4*>(s_r + row * NT_W + 4 * seg) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    } else {
+      const int R = a.radius;
+      for (int i = tid; i < NLH * NT_W; i += 256) {
+        const int ly = i / NT_W, lx = (i % NT_W) + NHALO;
+        float m = -INFINITY;
+        for (int d = -R; d <= R; ++d) m = fmaxf(m, s_s[ly * NLS + lx + d]);
+        s_r[ly * NT_W + (lx - NHALO)] = m;
+      }
+    }
     __syncthreads();
-    const int base = s_base;
-    for (int i = tid; i < n; i += 256)
-      if (base + i < a.cap) a.cand[(size_t)b * a.cap + base + i] = s_c[i];
+    // ---- column maxima, survival test; every thread owns NMS_SLOTS pixels whose verdicts stay in registers
+    float sc[NMS_SLOTS];
+    unsigned keep = 0;
+    unsigned pix[NMS_SLOTS];
+    auto verdict = [&](int slot, int iy, int ix, float s, float m) {
+      const int gy = y0 + NHALO + iy, gx = x0 + NHALO + ix;
+      sc[slot] = s;
+      pix[slot] = (unsigned)(gy * a.W + gx);
+      if (gy >= a.H || gx >= a.W) return;
+      const bool is_max = (RT == 4) ? (s == m) : (a.radius <= 0 || s == m);
+      const size_t o = ((size_t)b * a.H + gy) * a.W + gx;
+      if (a.scores_raw_out) a.scores_raw_out[o] = s;
+      if (a.scores_out) a.scores_out[o] = is_max ? s : 0.0f;
+      if (a.cand && is_max && s >= a.thr_f && gy >= a.border && gy < a.H - a.border && gx >= a.border &&
+          gx < a.W - a.border)
+        keep |= 1u << slot;
+    };
+    if constexpr (RT == 4) {
+#pragma unroll
+      for (int k = 0; k < NMS_SLOTS / 4; ++k) {
+        const int it = tid + k * 256;
+        const int ix = it & 63, rg = it >> 6;  // 4 consecutive interior rows 4*rg .. 4*rg+3 of column ix
+        float v[12], o[4];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) v[q] = s_r[(4 * rg + NHALO - 4 + q) * NT_W + ix];
+        window9x4(v, o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          verdict(k * 4 + q, 4 * rg + q, ix, s_s[(4 * rg + q + NHALO) * NLS + ix + NHALO], o[q]);
+      }
+    } else {
+      const int R = a.radius;
+#pragma unroll
+      for (int k = 0; k < NMS_SLOTS; ++k) {
+        const int i = tid + k * 256;
+        const int iy = i / NT_W, ix = i % NT_W;
+        float m = -INFINITY;
+        for (int d = -R; d <= R; ++d) m = fmaxf(m, s_r[(iy + NHALO + d) * NT_W + ix]);
+        verdict(k, iy, ix, s_s[(iy + NHALO) * NLS + ix + NHALO], m);
+      }
+    }
+    pend_n = 0;
+    if (a.cand) {
+      __syncthreads();  // s_s / s_r are dead: the candidate list takes their place
+      // workgroup-local compaction: one LDS atomic per wave, ONE global atomic per tile (per-candidate global atomics
+      // on the per-image counter serialise in L2)
+      const int mine = __popc(keep);
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      const int total = __shfl(incl, 63, 64);
+      int wbase = 0;
+      if (lane == 63 && total) wbase = atomicAdd(&s_cnt, total);
+      wbase = __shfl(wbase, 63, 64);
+      int pos = wbase + incl - mine;
+#pragma unroll
+      for (int k = 0; k < NMS_SLOTS; ++k)
+        if (keep & (1u << k)) s_c[pos++] = ((unsigned long long)__float_as_uint(sc[k]) << 32) | pix[k];
+      __syncthreads();
+      const int n = s_cnt;
+      if (n > NMS_PEND) {  // rare (plateaus): reserve and write synchronously
+        if (tid == 0) s_base = atomicAdd(&a.cand_count[b], n);
+        __syncthreads();
+        const int base = s_base;
+        for (int i = tid; i < n; i += 256)
+          if (base + i < a.cap) a.cand[(size_t)b * a.cap + base + i] = s_c[i];
+      } else if (n > 0) {   // park; the reservation's return value is consumed one tile later
+        if (tid < n) s_pend[tid] = s_c[tid];
+        if (tid == 0) ticket = atomicAdd(&a.cand_count[b], n);
+        pend_n = n; pend_b = b;
+      }
+    }
+    __syncthreads();  // the next tile overwrites s_s / s_cnt (and s_base once the ticket is read)
+  }
+  if (pend_n) {
+    if (tid == 0) s_base = ticket;
+    __syncthreads();
+    flush_pending();
   }
 }
 
@@ -276,7 +327,8 @@ float threshold_as_float(double thr) {
 }
 
 void launch_nms_tile(int loader, const NmsArgs& a, hipStream_t s) {
-  const int tiles = a.B * ((a.W + NT_W - 1) / NT_W) * ((a.H + NT_H - 1) / NT_H);
+  const int ntiles = a.B * ((a.W + NT_W - 1) / NT_W) * ((a.H + NT_H - 1) / NT_H);
+  const int tiles = ntiles < 5 * cu_count() ? ntiles : 5 * cu_count();  // persistent: 5 workgroups per CU (30 KB LDS each)
   const bool r4 = a.radius == 4;
   if (loader == 0) {
     if (r4) hipLaunchKernelGGL((k_nms_tile<0, 4>), dim3(tiles), dim3(256), 0, s, a);
