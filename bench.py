@@ -257,6 +257,29 @@ def main():
             fe1.run(imgs[:2], stream)
         torch.cuda.synchronize()
         out["latency_ms_single_pair"] = round((time.perf_counter() - t1) / 50 * 1e3, 4)
+        # the unit the reference actually runs per frame: the stereo match PLUS a second LightGlue call
+        # against the previous keyframe (VoEstimator.cc:243).  Emulated with left(p) vs left(p+1) on the features of
+        # the step itself; reported next to the headline metric, not instead of it.
+        idx = torch.arange(2 * P, device="cuda").view(P, 2)
+        idx[:, 1] = (idx[:, 0] + 2) % (2 * P)      # set 0 = left of pair p, set 1 = left of pair p + 1
+        idx = idx.reshape(-1)
+        m2 = torch.empty((P, args.max_kp), dtype=torch.int32, device="cuda")
+        s2 = torch.empty((P, args.max_kp), dtype=torch.float32, device="cuda")
+
+        def deployed_step():
+            fe.run(imgs, stream)
+            lg.match_batch_device(fe.kp.index_select(0, idx), fe.n.index_select(0, idx), fe.desc.index_select(0, idx), m2, s2, stream)
+
+        for _ in range(2):
+            deployed_step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(10):
+            deployed_step()
+        torch.cuda.synchronize()
+        out["deployed_unit"] = {"pairs_per_s": round(P * 10 / (time.perf_counter() - t2), 2),
+                                "unit": "SuperPoint x2 + LightGlue(L,R) + LightGlue(L, previous keyframe L) per pair",
+                                "keyframe_matches_last_step": int((m2 >= 0).sum().item())}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], args.max_kp)
         print(json.dumps(out), flush=True)

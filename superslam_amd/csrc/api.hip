@@ -1087,6 +1087,7 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
                  (float)lg->image_h, d, x, rope, s);
   // 3 launches per block: [projection fused into the previous FFN's tail] -> attention -> FFN(+ next projection).
   SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
+  g_timer.mark("lg_posenc_qkv0", s);
   for (int i = 0; i < kLgLayers; ++i) {
     // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
     launch_lg_attention(q, k, vt, lens, d, false, ctx, s);
@@ -1103,11 +1104,12 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
                     lg->md.as<_Float16>(), w->match_w, w->match_b, lg->logsig.as<float>(), s);
   }
   SSHIP_HIP_CHECK(hipGetLastError());
+  g_timer.mark("lg_layers_x9", s);
   launch_lg_sim(lg->md.as<_Float16>(), lens, d, lg->sim.as<float>(), s);
   launch_lg_assign(lg->sim.as<float>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->max_kp, m0, ms0,
                    0.1f /* filter_threshold */, s);
   SSHIP_HIP_CHECK(hipGetLastError());
-  g_timer.mark("lg_match", s);
+  g_timer.mark("lg_assign_filter", s);
   return SSHIP_OK;
 }
 
