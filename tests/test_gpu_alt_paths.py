@@ -89,3 +89,43 @@ def test_mfma_probe_reports_a_plausible_rate():
         print("mfma probe", "random" if rnd else "zero", "operands:", round(tf.value, 1), "TFLOP/s")
         assert 200.0 < tf.value < 3000.0
     assert _lib.lib().sship_mfma_probe(0, None) != 0   # null argument is an error, not a crash
+
+
+def test_two_matchers_on_shared_weights_run_concurrently(weights_dir):
+    """The reference's threading model (SuperSLAM.cc:129-133): the tracking thread's LightGlue (device descriptors)
+    and the loop-closure worker's LightGlue built from shared_engine() (host descriptors) match at the same time.
+    Handles own their streams and workspaces, the weights are immutable: results must equal the serial ones."""
+    import threading
+
+    from superslam_amd import LightGlue, SuperPoint, _lib
+    from superslam_amd.synth import make_stereo_pair
+
+    _lib.init(0)
+    sp = SuperPoint(weights_dir["sp_path"], 600, 0.005, 4, max_batch=2); assert sp.initialize(), sp.last_error
+    lg_a = LightGlue(weights_dir["lg_path"], 328, 200, max_keypoints=600); assert lg_a.initialize(), lg_a.last_error
+    lg_b = LightGlue(lg_a.shared_engine(), 328, 200, max_keypoints=600); assert lg_b.initialize(), lg_b.last_error
+    l, r = make_stereo_pair(200, 328, 31)
+    fl, fr = sp.extract_stereo(l, r)
+    hl, hr = lg_a.descriptors_to_host(fl.descriptors), lg_a.descriptors_to_host(fr.descriptors)
+    ref_a = lg_a.match(fl.keypoints, fl.descriptors, fr.keypoints, fr.descriptors)      # device overload
+    ref_b = lg_b.match(fr.keypoints, hr, fl.keypoints, hl)                               # host overload, other direction
+    out = {}
+
+    def work(tag, fn, n):
+        res = []
+        for _ in range(n):
+            res.append(fn())
+        out[tag] = res
+
+    ta = threading.Thread(target=work, args=("a", lambda: lg_a.match(fl.keypoints, fl.descriptors, fr.keypoints, fr.descriptors), 20))
+    tb = threading.Thread(target=work, args=("b", lambda: lg_b.match(fr.keypoints, hr, fl.keypoints, hl), 20))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    for res in out["a"]:
+        np.testing.assert_array_equal(res.matches0, ref_a.matches0)
+        np.testing.assert_array_equal(res.mscores0, ref_a.mscores0)
+    for res in out["b"]:
+        np.testing.assert_array_equal(res.matches0, ref_b.matches0)
+        np.testing.assert_array_equal(res.mscores0, ref_b.mscores0)
+    print("concurrent matchers: a", int((ref_a.matches0 >= 0).sum()), "matches, b", int((ref_b.matches0 >= 0).sum()))
+    del fl, fr
+    lg_a.close(); lg_b.close(); sp.close()
