@@ -256,6 +256,13 @@ static int upload_floats(const float* src, size_t n, float** dst) {
 }
 
 static bool g_inited = false;
+static int g_device = -1;  // the device sship_init selected; every API entry binds the calling thread to it
+// HIP's current device is per thread and defaults to 0: a second caller thread (the reference's loop-closure worker,
+// SuperSLAM.cc:129-133) on a rank that owns device != 0 would otherwise launch on the wrong GPU.
+static inline void bind_thread() {
+  static thread_local bool bound = false;
+  if (!bound && g_device >= 0) { (void)hipSetDevice(g_device); bound = true; }
+}
 static int require_device() {
   if (g_inited) return SSHIP_OK;
   return sship_init(-1);
@@ -299,6 +306,7 @@ extern "C" const char* sship_last_error(void) { return g_err.c_str(); }
 extern "C" void sship_set_log_callback(void (*cb)(int, const char*)) { g_log_cb = cb; }
 extern "C" void sship_set_profiling(int on) { g_profiling = on != 0; }
 extern "C" int sship_get_stage_timings(const char** labels, float* ms, int max_stages) {
+  bind_thread();
   g_timer.collect();
   int n = 0;
   for (auto& kv : g_timer.last) {
@@ -326,10 +334,12 @@ extern "C" int sship_init(int device) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(SSHIP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   g_inited = true;
+  g_device = cur;
   log_msg(2, "sship: device %d %s, %d CUs", cur, prop.gcnArchName, prop.multiProcessorCount);
   return SSHIP_OK;
 }
 extern "C" int sship_device_synchronize(void) {
+  bind_thread();
   SSHIP_HIP_CHECK(hipDeviceSynchronize());
   return SSHIP_OK;
 }
@@ -345,6 +355,7 @@ struct sship_pool {
   std::mutex mu;                // handles may be released from another thread (async keyframe copies)
 };
 extern "C" int sship_pool_create(int num_slots, int max_keypoints, int dim, sship_pool** out) {
+  bind_thread();
   if (!out || num_slots <= 0 || max_keypoints <= 0 || dim <= 0) return fail(SSHIP_ERR_INVALID, "pool_create: bad arguments");
   if (int rc = require_device()) return rc;
   auto* p = new sship_pool();
@@ -361,11 +372,13 @@ extern "C" int sship_pool_create(int num_slots, int max_keypoints, int dim, sshi
   return SSHIP_OK;
 }
 extern "C" void sship_pool_destroy(sship_pool* pool) {
+  bind_thread();
   if (!pool) return;
   for (void* s : pool->slots) if (s) (void)hipFree(s);
   delete pool;
 }
 extern "C" int sship_pool_acquire(sship_pool* pool) {
+  bind_thread();
   if (!pool) return -1;
   std::lock_guard<std::mutex> g(pool->mu);
   if (pool->free_slots.empty()) return -1;
@@ -374,15 +387,18 @@ extern "C" int sship_pool_acquire(sship_pool* pool) {
   return s;
 }
 extern "C" void sship_pool_release(sship_pool* pool, int slot) {
+  bind_thread();
   if (!pool || slot < 0 || slot >= (int)pool->slots.size()) return;
   std::lock_guard<std::mutex> g(pool->mu);
   pool->free_slots.push_back(slot);
 }
 extern "C" int sship_pool_in_use(const sship_pool* pool) {
+  bind_thread();
   if (!pool) return 0;
   return (int)pool->slots.size() - (int)pool->free_slots.size();
 }
 extern "C" void* sship_pool_slot_ptr(const sship_pool* pool, int slot) {
+  bind_thread();
   if (!pool || slot < 0 || slot >= (int)pool->slots.size()) return nullptr;
   return pool->slots[slot];
 }
@@ -392,6 +408,7 @@ extern "C" void* sship_pool_slot_ptr(const sship_pool* pool, int slot) {
 // ====================================================================================================
 extern "C" int sship_gather_normalize(const void* grid, int channels, int gh, int gw, const int* cell_h,
                                       const int* cell_w, int n, void* out, void* stream) {
+  bind_thread();
   if (n <= 0) return SSHIP_OK;  // DescriptorGather.cu:69
   if (!grid || !cell_h || !cell_w || !out || channels <= 0) return fail(SSHIP_ERR_INVALID, "gather_normalize: null argument");
   if (int rc = require_device()) return rc;
@@ -402,6 +419,7 @@ extern "C" int sship_gather_normalize(const void* grid, int channels, int gh, in
 }
 extern "C" int sship_gather_normalize_hwc(const void* grid, int channels, int gh, int gw, const int* cell_h,
                                           const int* cell_w, int n, void* out, void* stream) {
+  bind_thread();
   if (n <= 0) return SSHIP_OK;
   if (!grid || !cell_h || !cell_w || !out) return fail(SSHIP_ERR_INVALID, "gather_normalize_hwc: null argument");
   if (channels <= 0 || channels > 256 || channels % 4) return fail(SSHIP_ERR_INVALID, "gather_normalize_hwc: channels must be <= 256 and a multiple of 4");
@@ -412,6 +430,7 @@ extern "C" int sship_gather_normalize_hwc(const void* grid, int channels, int gh
   return SSHIP_OK;
 }
 extern "C" int sship_nms(const float* scores, int batch, int h, int w, int radius, float* out, void* stream) {
+  bind_thread();
   if (!scores || !out || batch <= 0 || h <= 0 || w <= 0) return fail(SSHIP_ERR_INVALID, "nms: bad arguments");
   if (radius < 0 || radius > 8) return fail(SSHIP_ERR_INVALID, "nms: radius must be in [0, 8]");
   if (int rc = require_device()) return rc;
@@ -424,6 +443,7 @@ extern "C" int sship_nms(const float* scores, int batch, int h, int w, int radiu
 extern "C" int sship_select_topk(const float* scores, int score_h, int score_w, int input_h, int input_w, double thr,
                                  int border, int max_kp, int desc_h, int desc_w, float* kp_xys, int* cell_h,
                                  int* cell_w, int* n_dev, int* n_cand_dev, void* stream) {
+  bind_thread();
   if (!scores || !kp_xys || !cell_h || !cell_w || !n_dev || score_h <= 0 || score_w <= 0)
     return fail(SSHIP_ERR_INVALID, "select_topk: bad arguments");
   if (max_kp <= 0 || max_kp > kMaxKp) return fail(SSHIP_ERR_INVALID, "select_topk: max_kp must be in [1, 4096]");
@@ -594,6 +614,7 @@ static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B
 }
 
 extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
+  bind_thread();
   if (!cfg || !out || !cfg->weights_path) return fail(SSHIP_ERR_INVALID, "sp_create: null argument");
   if (cfg->max_keypoints <= 0 || cfg->max_keypoints > kMaxKp) return fail(SSHIP_ERR_INVALID, "sp_create: max_keypoints must be in [1, 4096]");
   if (cfg->nms_radius < 0 || cfg->nms_radius > 8) return fail(SSHIP_ERR_INVALID, "sp_create: nms_radius must be in [0, 8]");
@@ -657,6 +678,7 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
   return SSHIP_OK;
 }
 extern "C" void sship_sp_destroy(sship_sp* sp) {
+  bind_thread();
   if (!sp) return;
   (void)hipDeviceSynchronize();
   for (ConvW* c : {&sp->c1b, &sp->c2a, &sp->c2b, &sp->c3a, &sp->c3b, &sp->c4a, &sp->c4b, &sp->cPa, &sp->cPb, &sp->cDa, &sp->cDb, &sp->cDb32})
@@ -669,11 +691,13 @@ extern "C" void sship_sp_destroy(sship_sp* sp) {
   if (sp->stream) (void)hipStreamDestroy(sp->stream);
   delete sp;
 }
-extern "C" sship_pool* sship_sp_pool(sship_sp* sp) { return sp ? sp->pool : nullptr; }
+extern "C" sship_pool* sship_sp_pool(sship_sp* sp) {
+  bind_thread(); return sp ? sp->pool : nullptr; }
 extern "C" int sship_sp_max_keypoints(const sship_sp* sp) { return sp ? sp->cfg.max_keypoints : 0; }
 
 extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, int batch, int h, int w, void* desc_out,
                                              float* kp_out, int* n_out, void* stream) {
+  bind_thread();
   if (!sp || !imgs || !desc_out || !kp_out || !n_out || batch <= 0) return fail(SSHIP_ERR_INVALID, "sp_extract_batch_device: bad arguments");
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
   if (int rc = sp_ensure(sp, batch, h, w)) return rc;
@@ -690,6 +714,7 @@ extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, 
 
 extern "C" int sship_sp_dense(sship_sp* sp, const uint8_t* imgs, int batch, int h, int w, float* scores, void* desc_grid,
                               float* logits, void* stream) {
+  bind_thread();
   if (!sp || !imgs || batch <= 0) return fail(SSHIP_ERR_INVALID, "sp_dense: bad arguments");
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
   if (int rc = sp_ensure(sp, batch, h, w)) return rc;
@@ -709,6 +734,7 @@ extern "C" int sship_sp_dense(sship_sp* sp, const uint8_t* imgs, int batch, int 
 }
 
 extern "C" int sship_mfma_probe(int random_operands, float* tflops) {
+  bind_thread();
   if (!tflops) return fail(SSHIP_ERR_INVALID, "mfma_probe: null argument");
   if (int rc = require_device()) return rc;
   SSHIP_HIP_CHECK(mfma_probe(random_operands != 0, tflops));
@@ -717,6 +743,7 @@ extern "C" int sship_mfma_probe(int random_operands, float* tflops) {
 
 extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms,
                                     double* macs) {
+  bind_thread();
   if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 11) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");
   if (batch > sp->wsB || h != sp->wsH || w != sp->wsW) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: run the network at this shape first");
   int H2, W2, H4, W4, Hc, Wc;
@@ -813,6 +840,7 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
 
 extern "C" int sship_sp_extract(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels,
                                 sship_features* out) {
+  bind_thread();
   if (!sp || !img || !out) return fail(SSHIP_ERR_INVALID, "sp_extract: null argument");
   const uint8_t* imgs[1] = {img};
   sship_features* outs[1] = {out};
@@ -820,12 +848,14 @@ extern "C" int sship_sp_extract(sship_sp* sp, const uint8_t* img, int h, int w, 
 }
 extern "C" int sship_sp_extract_stereo(sship_sp* sp, const uint8_t* left, const uint8_t* right, int h, int w, int stride,
                                        int channels, sship_features* out_left, sship_features* out_right) {
+  bind_thread();
   if (!sp || !left || !right || !out_left || !out_right) return fail(SSHIP_ERR_INVALID, "sp_extract_stereo: null argument");
   const uint8_t* imgs[2] = {left, right};
   sship_features* outs[2] = {out_left, out_right};
   return sp_extract_host(sp, imgs, 2, h, w, stride, channels, outs);
 }
 extern "C" int sship_desc_to_host(const void* desc_dev, int count, int dim, float* out) {
+  bind_thread();
   if (count <= 0 || !desc_dev) return SSHIP_OK;  // empty handle -> empty Mat (LightGlue.cc:461-462)
   if (!out || dim <= 0) return fail(SSHIP_ERR_INVALID, "desc_to_host: bad arguments");
   const size_t n = (size_t)count * dim;
@@ -836,6 +866,7 @@ extern "C" int sship_desc_to_host(const void* desc_dev, int count, int dim, floa
 }
 extern "C" int sship_sp_infer_host(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels, float* kp_xys,
                                    float* desc_f32, int* n) {
+  bind_thread();
   if (!sp || !img || !kp_xys || !desc_f32 || !n) return fail(SSHIP_ERR_INVALID, "sp_infer_host: null argument");
   sship_features f{};
   f.kp_xys = kp_xys;
@@ -882,6 +913,7 @@ static int lg_copies() {
 }
 
 extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
+  bind_thread();
   if (!path || !out) return fail(SSHIP_ERR_INVALID, "lg_weights_load: null argument");
   if (int rc = require_device()) return rc;
   StateDict sd; std::string err;
@@ -995,11 +1027,13 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
   return SSHIP_OK;
 }
 extern "C" void sship_lg_weights_retain(sship_lg_weights* w) {
+  bind_thread();
   if (!w) return;
   std::lock_guard<std::mutex> g(w->mu);
   ++w->refs;
 }
 extern "C" void sship_lg_weights_release(sship_lg_weights* w) {
+  bind_thread();
   if (!w) return;
   bool last;
   { std::lock_guard<std::mutex> g(w->mu); last = (--w->refs == 0); }
@@ -1016,6 +1050,7 @@ struct sship_lg {
 };
 
 extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, int max_kp, int max_pairs, sship_lg** out) {
+  bind_thread();
   if (!w || !out || image_w <= 0 || image_h <= 0) return fail(SSHIP_ERR_INVALID, "lg_create: bad arguments");
   if (max_kp <= 0 || max_kp > kMaxKp) return fail(SSHIP_ERR_INVALID, "lg_create: max_keypoints must be in [1, 4096]");
   if (max_pairs <= 0) max_pairs = 1;
@@ -1056,6 +1091,7 @@ extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, in
   return SSHIP_OK;
 }
 extern "C" void sship_lg_destroy(sship_lg* lg) {
+  bind_thread();
   if (!lg) return;
   (void)hipDeviceSynchronize();
   if (lg->stream) (void)hipStreamDestroy(lg->stream);
@@ -1115,6 +1151,7 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
 
 extern "C" int sship_lg_match_batch_device(sship_lg* lg, const float* kp, const int* n, const void* desc, int pairs,
                                            int32_t* m0, float* ms0, void* stream) {
+  bind_thread();
   if (!lg || !kp || !n || !desc || !m0 || !ms0) return fail(SSHIP_ERR_INVALID, "lg_match_batch_device: null argument");
   if (pairs <= 0 || pairs > lg->max_pairs) return fail(SSHIP_ERR_INVALID, "lg_match_batch_device: pairs exceeds max_pairs");
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lg->stream;
@@ -1149,6 +1186,7 @@ static int lg_match_common(sship_lg* lg, const float* kp0, int st0, int n0, cons
 
 extern "C" int sship_lg_match_device(sship_lg* lg, const float* kp0, int st0, int n0, const void* desc0, const float* kp1,
                                      int st1, int n1, const void* desc1, int32_t* matches0, float* mscores0) {
+  bind_thread();
   if (!lg || !kp0 || !kp1 || !desc0 || !desc1 || !matches0 || !mscores0) return fail(SSHIP_ERR_INVALID, "lg_match_device: null argument");
   if (n0 <= 0 || n1 <= 0) return fail(SSHIP_ERR_INVALID, "lg_match_device: empty keypoint set");  // LightGlue.cc:381-385
   if (n0 > lg->max_kp || n1 > lg->max_kp || st0 < 2 || st1 < 2) return fail(SSHIP_ERR_INVALID, "lg_match_device: n exceeds max_keypoints");
@@ -1161,6 +1199,7 @@ extern "C" int sship_lg_match_device(sship_lg* lg, const float* kp0, int st0, in
 }
 extern "C" int sship_lg_match_host(sship_lg* lg, const float* kp0, int st0, int n0, const float* desc0, const float* kp1,
                                    int st1, int n1, const float* desc1, int32_t* matches0, float* mscores0) {
+  bind_thread();
   if (!lg || !kp0 || !kp1 || !desc0 || !desc1 || !matches0 || !mscores0) return fail(SSHIP_ERR_INVALID, "lg_match_host: null argument");
   if (n0 <= 0 || n1 <= 0) return fail(SSHIP_ERR_INVALID, "lg_match_host: empty keypoint set");  // LightGlue.cc:294-295
   if (n0 > lg->max_kp || n1 > lg->max_kp || st0 < 2 || st1 < 2) return fail(SSHIP_ERR_INVALID, "lg_match_host: n exceeds max_keypoints");
@@ -1192,6 +1231,7 @@ extern "C" int sship_filter_matches(const int32_t* matches0, const float* mscore
 extern "C" int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs, int pairs, int h, int w,
                                            void* desc_out, float* kp_out, int* n_out, int32_t* m0, float* ms0,
                                            void* stream) {
+  bind_thread();
   if (!sp || !lg || !imgs || !desc_out || !kp_out || !n_out || !m0 || !ms0) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: null argument");
   if (pairs <= 0 || pairs > lg->max_pairs) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: pairs exceeds the matcher's max_pairs");
   if (sp->cfg.max_keypoints != lg->max_kp) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: extractor and matcher disagree on max_keypoints");

@@ -444,12 +444,9 @@ static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
   constexpr size_t smem = (size_t)(2 * P_IN_HALFS + P_W_HALFS) * 2 + 128 * 4;
   static_assert(smem <= 163840, "LDS budget");
   auto kern = conv3x3_pp<CIN, CT, POOL, FUSE1A>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // thread-safe one-time opt-in to > 64 KiB of dynamic LDS (C++11 magic static; handles may be created on any thread)
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (attr_rc != hipSuccess) return attr_rc;
   const int ncb = a.cout / CT;
   const int ntiles = a.B * ((a.W + P_TW - 1) / P_TW) * ((a.H + P_TH - 1) / P_TH);
   int gx = cu_count() / ncb;  // one persistent workgroup per CU

@@ -324,11 +324,8 @@ static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt
                         _Float16* ctx, hipStream_t s) {
   constexpr size_t smem = (size_t)QT * 4 * 34 * 64 * sizeof(float);
   constexpr int QPB = 32 * QT * (4 / KS);  // queries per workgroup
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  (void)attr_rc;  // thread-safe one-time opt-in (magic static)
   unsigned long long* tbuf = nullptr;
   const size_t nwg = (size_t)((d.NP + QPB - 1) / QPB) * 4 * d.S;
   static const bool trace_on = SSHIP_ATTN_TRACE_BUILD && getenv("SSHIP_ATTN_TRACE") != nullptr;
@@ -761,12 +758,9 @@ static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
   constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 16 * NT * 32 * 4 + 1792 * 4;
   static_assert(smem <= 163840, "LDS budget");
   auto kern = k_lg_ffn<NEXT_MT, HEADS, NT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // thread-safe one-time opt-in to > 64 KiB of dynamic LDS (C++11 magic static; handles may be created on any thread)
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (attr_rc != hipSuccess) return attr_rc;
   const int ntiles = tokens / (NT * 32);
   hipLaunchKernelGGL(kern, dim3(ntiles < cu_count() ? ntiles : cu_count()), dim3(512), smem, s, args...);  // one persistent workgroup per CU
   return hipGetLastError();

@@ -290,12 +290,9 @@ hipError_t launch_desc_head_sparse(const ConvW& da32, const ConvW& db32, const _
                                    hipStream_t s) {
   if (da32.cin != 128 || da32.cout != 256 || da32.ct != 32 || da32.ks != 3) return hipErrorInvalidValue;
   constexpr size_t smem = (size_t)64 * kDsPatchLd * 2 + (size_t)64 * kDhLd * 2 + 8 * 64 * 4 + 64 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_desc_head_sparse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // thread-safe one-time opt-in to > 64 KiB of dynamic LDS (C++11 magic static; handles may be created on any thread)
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_desc_head_sparse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (attr_rc != hipSuccess) return attr_rc;
   hipLaunchKernelGGL(k_desc_head_sparse, dim3((max_kp + 63) / 64, B), dim3(512), smem, s, a4b, Hc, Wc, cell_h, cell_w, n_dev,
                      max_kp, da32.w, da32.bias, db32.w, db32.bias, out, out_img_stride);
   return hipGetLastError();
