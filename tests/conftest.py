@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library is a build product (git-ignored): compile it in-tree when a fresh checkout runs the tests
+    before `__graft_entry__.build()` (hipcc cross-compiles gfx950 without a GPU; a few minutes, once)."""
+    from superslam_amd import build as B
+
+    if not os.path.exists(B.LIB):
+        B.build()
+    return B.LIB
+
+
 @pytest.fixture(scope="session")
 def weights_dir(tmp_path_factory):
     """Seeded synthetic weights written as safetensors (regenerated from the seed on every machine)."""
