@@ -205,7 +205,7 @@ static const Tensor* find_tensor(const StateDict& sd, const std::string& name, s
 // EACH of the q / k / v segments, so all waves have the same epilogue work).  The bias stays in logical order.
 static int upload_conv(const float* w, const float* bias, int cout, int cin, int ks, int ct, ConvW& out,
                        const std::vector<int>* row_map = nullptr, const std::vector<float>* row_scale = nullptr,
-                       int copies = 1, bool tile_interleave = false) {
+                       bool tile_interleave = false) {
   const int cout_pad = (cout + ct - 1) / ct * ct, mt_n = ct / 32, nchunk = cin / 64;
   const int nblocks = cout_pad / ct;
   std::vector<_Float16> pk((size_t)cout_pad * cin * ks * ks);
@@ -233,13 +233,9 @@ static int upload_conv(const float* w, const float* bias, int cout, int cin, int
     const int src = row_map ? (*row_map)[co] : co;
     bp[co] = bias ? bias[src] * (row_scale ? (*row_scale)[co] : 1.f) : 0.f;
   }
-  // replicas are skewed by 4352 B so the same element of different copies maps to different L2 channels
-  const size_t stride = pk.size() + (copies > 1 ? 2176 : 0);
-  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.w), stride * copies * sizeof(_Float16)));
+  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.w), pk.size() * sizeof(_Float16)));
   SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.bias), bp.size() * sizeof(float)));
-  for (int c = 0; c < copies; ++c)
-    SSHIP_HIP_CHECK(hipMemcpy(out.w + c * stride, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-  out.copies = copies; out.copy_stride = stride;
+  SSHIP_HIP_CHECK(hipMemcpy(out.w, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   SSHIP_HIP_CHECK(hipMemcpy(out.bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
   out.cin = cin; out.cout = cout; out.cout_pad = cout_pad; out.ks = ks; out.ct = ct;
   return SSHIP_OK;
@@ -905,13 +901,6 @@ static void lg_weights_free(sship_lg_weights* w) {
   delete w;
 }
 
-// Replicas of the weights k_lg_ffn streams (every workgroup walks the same fragments in the same order: replicas keep
-// the arithmetic bit-identical while spreading the traffic over L2 channels).  SUPERSLAM_HIP_LG_COPIES overrides.
-static int lg_copies() {
-  static const int v = getenv("SUPERSLAM_HIP_LG_COPIES") ? std::max(1, atoi(getenv("SUPERSLAM_HIP_LG_COPIES"))) : 1;  // measured: replicas do not help (profiles/r01_notes.txt)
-  return v;
-}
-
 extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
   bind_thread();
   if (!path || !out) return fail(SSHIP_ERR_INVALID, "lg_weights_load: null argument");
@@ -952,8 +941,8 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
         wf[(size_t)o * 512 + 256 + i] = (float)a;
       }
     }
-    if (int rc = upload_conv(wf.data(), bf.data(), 512, 512, 1, 64, d0, nullptr, nullptr, lg_copies())) return rc;
-    return upload_conv(w3->data.data(), b3->data.data(), 256, 512, 1, 32, d3, nullptr, nullptr, lg_copies());
+    if (int rc = upload_conv(wf.data(), bf.data(), 512, 512, 1, 64, d0)) return rc;
+    return upload_conv(w3->data.data(), b3->data.data(), 256, 512, 1, 32, d3);
   };
   auto vec = [&](const std::string& name, int n, float** dst) -> int {
     const Tensor* t = find_tensor(sd, name, {n}, err);
@@ -982,7 +971,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     {
       const Tensor* wt = find_tensor(sd, ps + "Wqkv.weight", {768, 256}, err);
       const Tensor* bs = find_tensor(sd, ps + "Wqkv.bias", {768}, err);
-      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 768, 256, 1, 96, w->qkv_t[i], &qkv_map, &qkv_scale, lg_copies(), true))) return bail(rc, g_err);
+      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 768, 256, 1, 96, w->qkv_t[i], &qkv_map, &qkv_scale, true))) return bail(rc, g_err);
     }
     if ((rc = ffn(ps, "out_proj", w->ffn0_s[i], w->ffn3_s[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(ps + "ffn.1.weight", 512, &w->ln_g_s[i]))) return bail(rc, err);
@@ -1000,7 +989,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     memcpy(bcat.data() + 256, bv->data.data(), 256 * 4);
     for (int r = 0; r < 256; ++r) scat[r] = cq_scale[r];
     if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 128, w->cqkv[i], nullptr, &scat))) return bail(rc, g_err);
-    if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 64, w->cqkv_t[i], nullptr, &scat, lg_copies(), true))) return bail(rc, g_err);
+    if ((rc = upload_conv(wcat.data(), bcat.data(), 512, 256, 1, 64, w->cqkv_t[i], nullptr, &scat, true))) return bail(rc, g_err);
     if ((rc = ffn(pc, "to_out", w->ffn0_c[i], w->ffn3_c[i]))) return bail(rc, err.empty() ? g_err : err);
     if ((rc = vec(pc + "ffn.1.weight", 512, &w->ln_g_c[i]))) return bail(rc, err);
     if ((rc = vec(pc + "ffn.1.bias", 512, &w->ln_b_c[i]))) return bail(rc, err);
@@ -1012,7 +1001,7 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
     {
       const Tensor* wt = find_tensor(sd, pa + "final_proj.weight", {256, 256}, err);
       const Tensor* bs = find_tensor(sd, pa + "final_proj.bias", {256}, err);
-      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 256, 256, 1, 32, w->final_t, nullptr, &fp_scale, lg_copies()))) return bail(rc, g_err);
+      if ((rc = upload_conv(wt->data.data(), bs->data.data(), 256, 256, 1, 32, w->final_t, nullptr, &fp_scale))) return bail(rc, g_err);
     }
     const Tensor* mw = find_tensor(sd, pa + "matchability.weight", {1, 256}, err);
     const Tensor* mb = mw ? find_tensor(sd, pa + "matchability.bias", {1}, err) : nullptr;

@@ -57,8 +57,6 @@ struct ConvW {          // one packed conv / linear layer on the device
   _Float16* w = nullptr;  // packed A-fragment order (igemm.h)
   float* bias = nullptr;  // [cout_pad]
   int cin = 0, cout = 0, cout_pad = 0, ks = 1, ct = 64;
-  int copies = 1;          // replicas of the packed weights (spread identical streaming reads over L2 channels)
-  size_t copy_stride = 0;  // halfs between replicas
 };
 // in: channels-last fp16 [B,H,W,cin]; out: [B,Ho,Wo,cout] fp16 (pool: floor(/2)).
 hipError_t sp_conv3x3_strip(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool,

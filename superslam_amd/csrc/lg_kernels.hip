@@ -403,8 +403,6 @@ __device__ __forceinline__ f2_t gelu2(f2_t y) {
 }
 struct FfnTail {
   int ntiles;                               // token tiles of the launch (the kernel is persistent: tile = blockIdx.x + k gridDim.x)
-  int copies0, copies3, copiesp;            // weight replicas (workgroup b reads replica b % copies)
-  size_t stride0, stride3, stridep;         // halfs between replicas
   IgemmArgs proj;          // epilogue arguments of the fused projection (wpack/bias/outputs/rope/np/flags/cout/H)
   unsigned long long* trace;  // SSHIP_FFN_TRACE: [workgroup][wave][12] shader-clock stamps of the workgroup's 2nd tile
   const float* match_w;    // final block only: matchability weights [256] ...
@@ -490,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   {
     // Weight fragments stream from L2 (no reuse between waves); keep TWO groups of G0 k-steps in flight in registers
     // so ~1k cycles of L2 latency are covered by the MFMAs of the previous group and the co-resident wave.
-    const _Float16* wp = w0q + (blockIdx.x % tail.copies0) * tail.stride0 + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
+    const _Float16* wp = w0q + (size_t)wave * (32 * 2 * 512) + lane * 8;  // packed [cb = wave][k16][mt][lane][8]
     h8_t ab[2][G0][2];
 #pragma unroll
     for (int i = 0; i < G0; ++i) {
@@ -598,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) ac2[n][r] = 0.f;
   {
-    const _Float16* wp = w3q + (blockIdx.x % tail.copies3) * tail.stride3 + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
+    const _Float16* wp = w3q + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
     h8_t a3[2][16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
@@ -651,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
-    const _Float16* wp = pj.wpack + (blockIdx.x % tail.copiesp) * tail.stridep + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
+    const _Float16* wp = pj.wpack + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;  // [cb = wave][k16][mt][lane][8]
     // M-tiles of the V segment run with SWAPPED operands (A = token tile, B = weights): the accumulator then holds
     // D[token][channel] with lane = channel and 8 consecutive registers = the 8 keys of one PV A-fragment unit, so V^T is
     // written in fragment order with one 16-byte store per lane (the 2-byte transposing stores it replaces were ~16x
@@ -798,8 +796,6 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
                    float* logsig, hipStream_t s) {
   const int tokens = d.S * d.NP;
   FfnTail t{};
-  t.copies0 = w0.copies; t.stride0 = w0.copy_stride; t.copies3 = w3.copies; t.stride3 = w3.copy_stride;
-  t.copiesp = 1; t.stridep = 0;
   const int nt = 2;  // 32-token N-tiles per workgroup tile
   t.ntiles = tokens / (nt * 32);
   static const bool trace_on = getenv("SSHIP_FFN_TRACE") != nullptr;
@@ -816,7 +812,6 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
     return;
   }
   t.proj = token_args(*next, x, 256, nullptr, 0, d);
-  t.copiesp = next->copies; t.stridep = next->copy_stride;
   t.proj.out0 = heads ? (void*)q : (void*)out; t.proj.out1 = k; t.proj.out2 = vt; t.proj.aux = rope;
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
