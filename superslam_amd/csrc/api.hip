@@ -1111,7 +1111,9 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   launch_lg_prep(kp, kp_stride, kp_seq_stride, lens, desc, desc_seq_stride, w->wr, (float)lg->image_w,
                  (float)lg->image_h, d, x, rope, s);
   // 3 launches per block: [projection fused into the previous FFN's tail] -> attention -> FFN(+ next projection).
-  SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
+  static const bool igemm_qkv0 = getenv("SUPERSLAM_HIP_LG_QKV0") && std::string(getenv("SUPERSLAM_HIP_LG_QKV0")) == "igemm";  // A/B
+  if (igemm_qkv0) SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
+  else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
   g_timer.mark("lg_posenc_qkv0", s);
   for (int i = 0; i < kLgLayers; ++i) {
     // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]

@@ -413,7 +413,8 @@ struct FfnTail {
 // three GEMMs need 64 B/clk/CU of L2 -> L1 bandwidth to keep the matrix pipe busy (= the TCP's peak, so the kernel
 // was bound by the weight stream: 1.18 MB per 64 tokens).  NT = 4 halves the stream per token (throughput batches);
 // NT = 2 keeps more workgroups in flight for a few pairs (latency mode).
-template <int NEXT_MT, bool HEADS, int NT>
+// PROJ: projection only (the first layer's Wqkv has no FFN in front of it): stage the tile, run the fused projection.
+template <int NEXT_MT, bool HEADS, int NT, bool PROJ>
 __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                 const float* __restrict__ b0, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   // ffn.0 bias, LayerNorm gamma / beta, ffn.3 bias: the same for every tile of this persistent workgroup -> LDS once
   // (they were 28 dependent L2 round trips per lane and tile, right on the critical path between the GEMM phases)
   float* s_par = reinterpret_cast<float*>(s_red) + 16 * NTOK;  // [b0 512 | gamma 512 | beta 512 | b3 256]
-  for (int i = threadIdx.x; i < 1792; i += 512)
+  for (int i = threadIdx.x; i < (PROJ ? 0 : 1792); i += 512)
     s_par[i] = i < 512 ? b0[i] : i < 1024 ? gamma[i - 512] : i < 1536 ? beta[i - 1024] : b3[i - 1536];
   // Token-tile staging by LDS-DMA (global_load_lds_dwordx4): one instruction per token row - lanes 0..31 fetch the 32
   // 16-byte units of x[token], lanes 32..63 those of ctx[token]; the row lands lane-linear at its (padded) LDS row.
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     if (tail.trace && it == 1 && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
   };
   stamp(0);
+  if constexpr (!PROJ) {
   // ---- ffn.0 : rows [64 wave, +64) x NTOK tokens, K = 512 ----
   f16x_t acc[2][NT];
 #pragma unroll
@@ -638,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     }
   }
   stamp(6);
+  }  // !PROJ
   if constexpr (NEXT_MT > 0) {
     __syncthreads();
     stamp(7);
@@ -696,6 +699,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         }
       }
       stamp(8);
+      if (PROJ && NT == 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);  // the epilogue covers the DMA
       if (SSHIP_FFN_ABL & 32) return;
       if constexpr (HEADS) {
         const int NP = pj.np, nt32 = NP >> 5;
@@ -747,15 +751,16 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     stage_tile(tile + gridDim.x, s_xn, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (has_next) __syncthreads();  // DMA data (awaited per wave above) visible to every wave; s_red / tile buffers quiescent
   stamp(10);
   }  // tile loop
 }
-template <int NEXT_MT, bool HEADS, int NT, typename... A>
+template <int NEXT_MT, bool HEADS, int NT, bool PROJ, typename... A>
 static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
   constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 16 * NT * 32 * 4 + 1792 * 4;
   static_assert(smem <= 163840, "LDS budget");
-  auto kern = k_lg_ffn<NEXT_MT, HEADS, NT>;
+  auto kern = k_lg_ffn<NEXT_MT, HEADS, NT, PROJ>;
   // thread-safe one-time opt-in to > 64 KiB of dynamic LDS (C++11 magic static; handles may be created on any thread)
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr_rc != hipSuccess) return attr_rc;
@@ -786,7 +791,7 @@ template <int NEXT_MT, bool HEADS, typename... A>
 static hipError_t launch_ffn(int nt, int tokens, hipStream_t s, A... args) {
   (void)nt;  // only the 64-token tile is instantiated: 128 tokens measured 9 % slower end to end (1.25 tiles per CU at
              // 32 pairs, single tile buffer) and no longer fits the register file next to the prefetch buffers
-  return launch_ffn_nt<NEXT_MT, HEADS, 2>(tokens, s, args...);
+  return launch_ffn_nt<NEXT_MT, HEADS, 2, false>(tokens, s, args...);
 }
 // next == nullptr: plain FFN.  Otherwise the projection `next` (packed with ct = 32 * next_mt rows per wave) runs on
 // the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
@@ -820,6 +825,22 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   else if (heads && mt == 2) (void)launch_ffn<2, true>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
   else (void)launch_ffn<1, false>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
   if (trace_on) ffn_trace_report(trace_buf, trace_wg, mt, s);
+}
+
+// The first SelfBlock's Wqkv (no FFN in front of it): the FFN kernel's fused projection on its own - same persistent
+// tile loop, LDS-DMA staging, prefetched weight stream and tile-interleaved rows as the other 17 projections.
+hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int rope_segs, int t_seg, const float* rope, _Float16* q,
+                                _Float16* k, _Float16* vt, hipStream_t s) {
+  if (next.cout != 768) return hipErrorInvalidValue;
+  const int tokens = d.S * d.NP;
+  FfnTail t{};
+  t.ntiles = tokens / 64;
+  t.proj = token_args(next, x, 256, nullptr, 0, d);
+  t.proj.out0 = q; t.proj.out1 = k; t.proj.out2 = vt; t.proj.aux = rope;
+  t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
+  return launch_ffn_nt<3, true, 2, true>(tokens, s, (const _Float16*)x, (const _Float16*)nullptr, (const float*)nullptr,
+                                         (const float*)nullptr, (const float*)nullptr, (const _Float16*)nullptr,
+                                         (const float*)nullptr, x, t);
 }
 
 // ---------------------------------------------------------------------------------------------------
