@@ -28,6 +28,10 @@
 #ifndef SSHIP_PP_EPI
 #define SSHIP_PP_EPI -1
 #endif
+// staging geometry hoisted out of the tile loop: -1 = per-kernel default (128-input-channel layers only), 0 / 1 force
+#ifndef SSHIP_PP_HOIST
+#define SSHIP_PP_HOIST -1
+#endif
 // role tracing (SSHIP_PP_TRACE=1 at run time) is compiled in only on request: it costs registers in the fused kernel
 #ifndef SSHIP_PP_TRACE_BUILD
 #define SSHIP_PP_TRACE_BUILD 0
@@ -63,6 +67,7 @@ __device__ __forceinline__ int pp_lds(int row, int col, int unit) {
 template <int CIN, int CT, bool POOL, bool FUSE1A>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   constexpr int MT = CT / 32, NCHUNK = CIN / 64;
+  constexpr int HOIST_GEOMETRY = SSHIP_PP_HOIST < 0 ? (CIN == 128 ? 1 : 0) : SSHIP_PP_HOIST;
   constexpr int EPI_MFMA = SSHIP_PP_EPI < 0 ? (CIN == 128 ? 2 : 0) : (SSHIP_PP_EPI > 2 * MT ? 2 * MT : SSHIP_PP_EPI);
   static_assert(NCHUNK * 9 * 4 * MT * 512 == P_W_HALFS, "weights must fill exactly 72 KiB");
   static_assert(!FUSE1A || CIN == 64, "conv1a fusion feeds a 64-channel layer");
@@ -120,7 +125,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       tile_coords(tile_of(item), b, y0, x0);
       const int chunk = item % NCHUNK;
       int gtv = gt;
-      asm volatile("" : "+v"(gtv));  // opaque: keeps the per-iteration geometry from being hoisted into ~50 live VGPRs
+      // CIN = 64 (MT = 2, ~250 VGPRs): opaque, keeps the per-iteration geometry from being hoisted into ~50 live VGPRs.
+      // CIN = 128 (MT = 1, ~165 VGPRs) has the registers: the offsets are computed once per launch instead of ~330
+      // integer instructions per half-step in the (critical) data-movement role.
+      if (HOIST_GEOMETRY == 0) asm volatile("" : "+v"(gtv));
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
       if (interior) {
         const _Float16* base = p.in + ((size_t)(b * p.H + (y0 - 1)) * p.W + (x0 - 1)) * CIN + chunk * 64;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       tile_coords(tile_of(item), b, y0, x0);
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
       int gtv = gt;
-      asm volatile("" : "+v"(gtv));
+      if (HOIST_GEOMETRY == 0) asm volatile("" : "+v"(gtv));
 #pragma unroll
       for (int i = 0; i < P_IN_IT; ++i) {
         const int u = gtv + i * 256;
