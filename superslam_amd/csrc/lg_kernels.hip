@@ -887,16 +887,19 @@ __global__ __launch_bounds__(256) void k_assign_row_lse(const float* __restrict_
   sum = wave_sum(sum);
   if (lane == 0) ws[(size_t)pair * 5 * NP + i] = m + logf(sum);
 }
-__global__ __launch_bounds__(256) void k_assign_col_lse(const float* __restrict__ sim, const int* __restrict__ lens,
+// column passes: 64 columns x kColRG row groups per workgroup (4 groups left every thread a 150-step dependent chain of
+// online-softmax updates: 58 us per 64 pairs)
+constexpr int kColRG = 16;
+__global__ __launch_bounds__(64 * kColRG) void k_assign_col_lse(const float* __restrict__ sim, const int* __restrict__ lens,
                                                         int NP, float* __restrict__ ws) {
-  __shared__ float s_m[4][64], s_s[4][64];
+  __shared__ float s_m[kColRG][64], s_s[kColRG][64];
   const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + cl;
   const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   float m = -INFINITY, sum = 0.f;
   if (j < n1) {
     const float* col = sim + (size_t)pair * NP * NP + j;
-    for (int i = rg; i < n0; i += 4) {
+    for (int i = rg; i < n0; i += kColRG) {
       const float v = col[(size_t)i * NP];
       const float mn = fmaxf(m, v);
       sum = sum * expf(m - mn) + expf(v - mn);
@@ -907,9 +910,9 @@ __global__ __launch_bounds__(256) void k_assign_col_lse(const float* __restrict_
   __syncthreads();
   if (rg == 0 && j < n1) {
     float M = s_m[0][cl];
-    for (int g = 1; g < 4; ++g) M = fmaxf(M, s_m[g][cl]);
+    for (int g = 1; g < kColRG; ++g) M = fmaxf(M, s_m[g][cl]);
     float S = 0.f;
-    for (int g = 0; g < 4; ++g) if (s_m[g][cl] > -INFINITY) S += s_s[g][cl] * expf(s_m[g][cl] - M);
+    for (int g = 0; g < kColRG; ++g) if (s_m[g][cl] > -INFINITY) S += s_s[g][cl] * expf(s_m[g][cl] - M);
     ws[(size_t)pair * 5 * NP + NP + j] = M + logf(S);
   }
 }
@@ -937,10 +940,10 @@ __global__ __launch_bounds__(256) void k_assign_row_arg(const float* __restrict_
   }
   if (lane == 0) { w[2 * NP + i] = best; reinterpret_cast<int*>(w)[3 * NP + i] = bj; }
 }
-__global__ __launch_bounds__(256) void k_assign_col_arg(const float* __restrict__ sim, const float* __restrict__ logsig,
+__global__ __launch_bounds__(64 * kColRG) void k_assign_col_arg(const float* __restrict__ sim, const float* __restrict__ logsig,
                                                         const int* __restrict__ lens, int NP, float* __restrict__ ws) {
-  __shared__ float s_v[4][64];
-  __shared__ int s_i[4][64];
+  __shared__ float s_v[kColRG][64];
+  __shared__ int s_i[kColRG][64];
   const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + cl;
   const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(256) void k_assign_col_arg(const float* __restrict_
     const float* col = sim + (size_t)pair * NP * NP + j;
     const float* ls0 = logsig + (size_t)(2 * pair) * NP;
     const float lj = w[NP + j], ls1 = logsig[(size_t)(2 * pair + 1) * NP + j];
-    for (int i = rg; i < n0; i += 4) {
+    for (int i = rg; i < n0; i += kColRG) {
       const float sv = col[(size_t)i * NP];
       const float v = ((sv - w[i]) + (sv - lj)) + (ls0[i] + ls1);
       if (v > best) { best = v; bi = i; }
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(256) void k_assign_col_arg(const float* __restrict_
   s_v[rg][cl] = best; s_i[rg][cl] = bi;
   __syncthreads();
   if (rg == 0 && j < n1) {
-    for (int g = 1; g < 4; ++g)
+    for (int g = 1; g < kColRG; ++g)
       if (s_v[g][cl] > best || (s_v[g][cl] == best && s_i[g][cl] < bi)) { best = s_v[g][cl]; bi = s_i[g][cl]; }
     reinterpret_cast<int*>(w)[4 * NP + j] = bi;
   }
@@ -987,9 +990,9 @@ void launch_lg_assign(const float* sim, const float* logsig, const int* lens, Lg
                       int32_t* matches0, float* mscores0, float thr, hipStream_t s) {
   const int P = d.S / 2;
   hipLaunchKernelGGL(k_assign_row_lse, dim3(d.NP / 4, P), dim3(256), 0, s, sim, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_col_lse, dim3(d.NP / 64, P), dim3(256), 0, s, sim, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_col_lse, dim3(d.NP / 64, P), dim3(64 * kColRG), 0, s, sim, lens, d.NP, ws);
   hipLaunchKernelGGL(k_assign_row_arg, dim3(d.NP / 4, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_col_arg, dim3(d.NP / 64, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_col_arg, dim3(d.NP / 64, P), dim3(64 * kColRG), 0, s, sim, logsig, lens, d.NP, ws);
   hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr,
                      matches0, mscores0);
 }
