@@ -420,11 +420,11 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
                                                 const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
   constexpr int NTOK = NT * 32;
-  constexpr int G0 = NT == 2 ? 8 : 4;  // ffn.0 k-steps per register-prefetch group (acc takes 32 NT registers)
+  constexpr int G0 = NT <= 2 ? 8 : 4;  // ffn.0 k-steps per register-prefetch group (acc takes 32 NT registers)
   constexpr int XBUF = NTOK * kFfnLd;  // halfs per token-tile buffer
   extern __shared__ __attribute__((aligned(16))) char ffn_smem[];
   _Float16* s_xbuf = reinterpret_cast<_Float16*>(ffn_smem);                                   // [NBUF][NTOK][kFfnLd]
-  float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_xbuf + (NT == 2 ? 2 : 1) * XBUF);  // [16][NTOK]: per-wave sums, sums of squares
+  float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_xbuf + (NT <= 2 ? 2 : 1) * XBUF);  // [16][NTOK]: per-wave sums, sums of squares
   // ffn.0 bias, LayerNorm gamma / beta, ffn.3 bias: the same for every tile of this persistent workgroup -> LDS once
   // (they were 28 dependent L2 round trips per lane and tile, right on the critical path between the GEMM phases)
   float* s_par = reinterpret_cast<float*>(s_red) + 16 * NTOK;  // [b0 512 | gamma 512 | beta 512 | b3 256]
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   int it = 0;
 #pragma unroll 1
   for (int tile = tile0; tile < tail.ntiles; tile += gridDim.x, ++it) {
-  _Float16* s_x = s_xbuf + (NT == 2 ? (it & 1) : 0) * XBUF;
-  _Float16* s_xn = s_xbuf + (NT == 2 ? ((it + 1) & 1) : 0) * XBUF;
+  _Float16* s_x = s_xbuf + (NT <= 2 ? (it & 1) : 0) * XBUF;
+  _Float16* s_xn = s_xbuf + (NT <= 2 ? ((it + 1) & 1) : 0) * XBUF;
   const bool has_next = tile + (int)gridDim.x < tail.ntiles;
   const size_t t0 = (size_t)tile * NTOK;
   // Everything below that does not depend on the tile (weight fragments, biases, LayerNorm parameters) is loop
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   // every wave has passed the LayerNorm barriers, i.e. finished the previous tile: its buffer takes the next tile.
   // Issued here because no weight prefetch is in flight (an older DMA would sit in front of it in the in-order vmcnt
   // queue) and the GELU math + ffn.3 that follow cover the HBM latency.
-  if (NT == 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);
+  if (NT <= 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);
   // the residual operand (this lane's 16 x values per N-tile) is requested before the GELU math: its L2 round trip
   // used to sit between the ffn.3 loop and the barrier that opens the fused projection
   h4_t xres[4][NT];
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       constexpr int VMASK = decltype(vmask_c)::value;
       // weight fragments: two groups of GT k-steps in flight in registers, pinned above the MFMAs of the previous
       // group (a plain unrolled loop made hipcc wait for every fragment right before its MFMA: 28k clocks for 96 MFMAs)
-      constexpr int GT = NT == 2 ? 4 : 2;
+      constexpr int GT = NT <= 2 ? 4 : 2;
       h8_t at[2][GT][NEXT_MT];
 #pragma unroll
       for (int i = 0; i < GT; ++i)
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         }
       }
       stamp(8);
-      if (PROJ && NT == 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);  // the epilogue covers the DMA
+      if (PROJ && NT <= 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);  // the epilogue covers the DMA
       if (SSHIP_FFN_ABL & 32) return;
       if constexpr (HEADS) {
         const int NP = pj.np, nt32 = NP >> 5;
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     }
   }
   stamp(9);
-  if (NT != 2 && has_next) {  // single tile buffer: synchronous restage
+  if (NT > 2 && has_next) {  // single tile buffer: synchronous restage
     __syncthreads();
     stage_tile(tile + gridDim.x, s_xn, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 }
 template <int NEXT_MT, bool HEADS, int NT, bool PROJ, typename... A>
 static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
-  constexpr size_t smem = (size_t)(NT == 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 16 * NT * 32 * 4 + 1792 * 4;
+  constexpr size_t smem = (size_t)(NT <= 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 16 * NT * 32 * 4 + 1792 * 4;
   static_assert(smem <= 163840, "LDS budget");
   auto kern = k_lg_ffn<NEXT_MT, HEADS, NT, PROJ>;
   // thread-safe one-time opt-in to > 64 KiB of dynamic LDS (C++11 magic static; handles may be created on any thread)
@@ -789,9 +789,10 @@ static void ffn_trace_report(unsigned long long* dev, int nwg, int next_mt, hipS
 }
 template <int NEXT_MT, bool HEADS, typename... A>
 static hipError_t launch_ffn(int nt, int tokens, hipStream_t s, A... args) {
-  (void)nt;  // only the 64-token tile is instantiated: 128 tokens measured 9 % slower end to end (1.25 tiles per CU at
-             // 32 pairs, single tile buffer) and no longer fits the register file next to the prefetch buffers
-  return launch_ffn_nt<NEXT_MT, HEADS, 2, false>(tokens, s, args...);
+  // 64-token tiles for throughput, 32-token tiles when the launch cannot even give half of the CUs a workgroup (a few
+  // pairs: twice the workgroups in flight, half the MFMA work per weight stream).  128 tokens measured 9 % slower end to
+  // end (1.25 tiles per CU at 32 pairs, single tile buffer) and no longer fits the registers: not instantiated.
+  return nt == 1 ? launch_ffn_nt<NEXT_MT, HEADS, 1, false>(tokens, s, args...) : launch_ffn_nt<NEXT_MT, HEADS, 2, false>(tokens, s, args...);
 }
 // next == nullptr: plain FFN.  Otherwise the projection `next` (packed with ct = 32 * next_mt rows per wave) runs on
 // the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
@@ -801,7 +802,8 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
                    float* logsig, hipStream_t s) {
   const int tokens = d.S * d.NP;
   FfnTail t{};
-  const int nt = 2;  // 32-token N-tiles per workgroup tile
+  static const int nt_env = getenv("SUPERSLAM_HIP_FFN_NT") ? atoi(getenv("SUPERSLAM_HIP_FFN_NT")) : 0;  // A/B: 1 | 2
+  const int nt = nt_env == 1 || nt_env == 2 ? nt_env : (tokens / 64 < cu_count() / 2 ? 1 : 2);  // 32-token N-tiles per workgroup tile
   t.ntiles = tokens / (nt * 32);
   static const bool trace_on = getenv("SSHIP_FFN_TRACE") != nullptr;
   static unsigned long long* trace_buf = nullptr;
@@ -834,13 +836,15 @@ hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int ro
   if (next.cout != 768) return hipErrorInvalidValue;
   const int tokens = d.S * d.NP;
   FfnTail t{};
-  t.ntiles = tokens / 64;
+  const int nt = tokens / 64 < cu_count() / 2 ? 1 : 2;  // as launch_lg_ffn: 32-token tiles for a few pairs
+  t.ntiles = tokens / (nt * 32);
   t.proj = token_args(next, x, 256, nullptr, 0, d);
   t.proj.out0 = q; t.proj.out1 = k; t.proj.out2 = vt; t.proj.aux = rope;
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
-  return launch_ffn_nt<3, true, 2, true>(tokens, s, (const _Float16*)x, (const _Float16*)nullptr, (const float*)nullptr,
-                                         (const float*)nullptr, (const float*)nullptr, (const _Float16*)nullptr,
-                                         (const float*)nullptr, x, t);
+  const _Float16* nh = nullptr;
+  const float* nf = nullptr;
+  return nt == 1 ? launch_ffn_nt<3, true, 1, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t)
+                 : launch_ffn_nt<3, true, 2, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t);
 }
 
 // ---------------------------------------------------------------------------------------------------
