@@ -628,7 +628,7 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
                       {"conv2b", 64, 64, 3, 64, &sp->c2b}, {"conv3a", 128, 64, 3, 64, &sp->c3a},
                       {"conv3b", 128, 128, 3, 32, &sp->c3b}, {"conv4a", 128, 128, 3, 32, &sp->c4a},
                       {"conv4b", 128, 128, 3, 32, &sp->c4b}, {"convPa", 256, 128, 3, 32, &sp->cPa},
-                      {"convPb", 65, 256, 1, 128, &sp->cPb}, {"convDa", 256, 128, 3, 32, &sp->cDa},
+                      {"convPb", 65, 256, 1, 96, &sp->cPb}, {"convDa", 256, 128, 3, 32, &sp->cDa},
                       {"convDb", 256, 256, 1, 128, &sp->cDb}};
   for (const L& l : layers) {
     const Tensor* w = find_tensor(sd, std::string(l.name) + ".weight", {l.cout, l.cin, l.ks, l.ks}, err);

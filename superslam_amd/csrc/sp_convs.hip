@@ -27,7 +27,7 @@ hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int os
   IgemmArgs a = conv_args(w, in, B, H, W);
   a.out0 = out; a.ostride = ostride;
   if (w.cin != 256) return hipErrorInvalidValue;
-  return launch_igemm<1, 256, 128, 4, EpiF32>(a, w.cout_pad, s);
+  return launch_igemm<1, 256, 96, 4, EpiF32>(a, w.cout_pad, s);  // 65 rows: three M-tiles, not four
 }
 
 // ---------------------------------------------------------------------------------------------------
