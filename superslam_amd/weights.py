@@ -54,28 +54,47 @@ def _lin(g, out_f, in_f, gain=1.0, bias_scale=0.02):
     return w.contiguous(), b.contiguous()
 
 
-def make_lightglue_weights(seed: int = 1, residual_gain: float = 0.05, assign_gain: float = 24.0) -> dict:
+# Per-layer gains on the q/k rows of SelfBlock.Wqkv and on CrossBlock.to_qk.  With he-style unit-variance rows and a
+# unit-norm descriptor stream the attention logits would have std ~0.004, i.e. every softmax would be uniform and a
+# parity test could not tell attention from averaging (round-1 VERDICT, "What's weak" 1).  These constants were
+# calibrated once (scripts/calibrate_lg_gains.py) so that the logits of every layer have std ~2 on the n97x130 fixture;
+# they are literals, not computed at import, so the state dict stays bit-reproducible across machines.
+LG_SELF_QK_GAIN = (22.0, 18.0, 16.0, 14.0, 13.0, 12.0, 11.0, 10.0, 9.8)
+LG_CROSS_QK_GAIN = (18.0, 15.0, 14.0, 12.0, 11.0, 10.0, 9.5, 9.5, 8.7)
+LG_POSENC_GAIN = 6.0
+
+
+def make_lightglue_weights(seed: int = 1, residual_gain: float = 0.05, assign_gain: float = 24.0,
+                           self_qk_gain=LG_SELF_QK_GAIN, cross_qk_gain=LG_CROSS_QK_GAIN,
+                           posenc_gain: float = LG_POSENC_GAIN) -> dict:
     """Seeded LightGlue(features='superpoint') state dict, upstream key layout.
 
     ``residual_gain`` keeps each block's update small against the unit-norm descriptor stream and
     ``assign_gain`` makes final_proj a scaled near-identity, so the random-weight matcher behaves
     like a sharpened mutual-nearest-neighbour matcher: synthetic stereo pairs then produce a
-    realistic number of confident matches instead of an all -1 output.
+    realistic number of confident matches instead of an all -1 output.  ``self_qk_gain`` /
+    ``cross_qk_gain`` / ``posenc_gain`` make the attention softmaxes peaked and position dependent
+    (see the constants above) so that errors in QK^T, the softmax, rotary or the keypoint
+    normalisation move matches0 / mscores0 by more than the parity tolerances.
     """
     g = torch.Generator(device="cpu").manual_seed(seed)
     sd = {}
-    sd["posenc.Wr.weight"] = (torch.randn((32, 2), generator=g, dtype=torch.float32) * 1.0).contiguous()
+    sd["posenc.Wr.weight"] = (torch.randn((32, 2), generator=g, dtype=torch.float32) * posenc_gain).contiguous()
     d = LG_DIM
     for i in range(LG_LAYERS):
         p = f"transformers.{i}.self_attn."
-        sd[p + "Wqkv.weight"], sd[p + "Wqkv.bias"] = _lin(g, 3 * d, d)
+        w, b = _lin(g, 3 * d, d)
+        # rows are (head, dim, {q,k,v}) - unflatten(-1, (4, 64, 3)): scale the q and k rows only
+        w.view(LG_HEADS, d // LG_HEADS, 3, d)[:, :, 0:2] *= self_qk_gain[i]
+        b.view(LG_HEADS, d // LG_HEADS, 3)[:, :, 0:2] *= self_qk_gain[i]
+        sd[p + "Wqkv.weight"], sd[p + "Wqkv.bias"] = w, b
         sd[p + "out_proj.weight"], sd[p + "out_proj.bias"] = _lin(g, d, d)
         sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"] = _lin(g, 2 * d, 2 * d)
         sd[p + "ffn.1.weight"] = (1.0 + 0.1 * torch.randn(2 * d, generator=g)).contiguous()
         sd[p + "ffn.1.bias"] = (0.05 * torch.randn(2 * d, generator=g)).contiguous()
         sd[p + "ffn.3.weight"], sd[p + "ffn.3.bias"] = _lin(g, d, 2 * d, gain=residual_gain, bias_scale=0.002)
         p = f"transformers.{i}.cross_attn."
-        sd[p + "to_qk.weight"], sd[p + "to_qk.bias"] = _lin(g, d, d)
+        sd[p + "to_qk.weight"], sd[p + "to_qk.bias"] = _lin(g, d, d, gain=cross_qk_gain[i], bias_scale=0.02 * cross_qk_gain[i])
         sd[p + "to_v.weight"], sd[p + "to_v.bias"] = _lin(g, d, d)
         sd[p + "to_out.weight"], sd[p + "to_out.bias"] = _lin(g, d, d)
         sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"] = _lin(g, 2 * d, 2 * d)

@@ -109,7 +109,10 @@ def main():
         lgv[tag + "_kpts0"] = k0[0].numpy(); lgv[tag + "_kpts1"] = k1[0].numpy()
         lgv[tag + "_desc0"] = d0h[0].numpy(); lgv[tag + "_desc1"] = d1h[0].numpy()
         lgv[tag + "_matches0"] = m0[0].numpy(); lgv[tag + "_mscores0"] = ms0[0].numpy()
-        lgv[tag + "_x0"] = it["x0"][0].float().numpy(); lgv[tag + "_sim"] = it["sim"][0].float().numpy()
+        lgv[tag + "_sim"] = it["sim"][0].float().numpy()
+        for layer in (0, 8):   # residual streams after the first and the last layer (both images)
+            lgv[f"{tag}_x0_l{layer}"] = it["x0_layers"][layer][0].float().numpy()
+            lgv[f"{tag}_x1_l{layer}"] = it["x1_layers"][layer][0].float().numpy()
     np.savez_compressed(os.path.join(OUT, "lightglue_selfcheck.npz"), **lgv)
 
     # ---- G6: host pre/post known-answer tables (hand-checkable) ----

@@ -166,10 +166,14 @@ def test_lightglue_selfcheck_vectors(golden_dir):
         d0 = torch.from_numpy(g[tag + "_desc0"].astype(np.float32))[None]
         d1 = torch.from_numpy(g[tag + "_desc1"].astype(np.float32))[None]
         with torch.no_grad():
-            m64, s64 = L.match(lg, k0, d0, k1, d1)
+            m64, s64, it = L.match(lg, k0, d0, k1, d1, return_internals=True)
             m32, s32 = L.match(lg, k0, d0, k1, d1, dtype=torch.float32)
         np.testing.assert_array_equal(m64[0].numpy(), g[tag + "_matches0"])
         np.testing.assert_allclose(s64[0].numpy(), g[tag + "_mscores0"], atol=1e-6)
+        np.testing.assert_allclose(it["sim"][0].numpy(), g[tag + "_sim"], rtol=1e-5, atol=1e-5)
+        for layer in (0, 8):   # the per-layer residual streams the GPU debug ABI is compared against
+            np.testing.assert_allclose(it["x0_layers"][layer][0].numpy(), g[f"{tag}_x0_l{layer}"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(it["x1_layers"][layer][0].numpy(), g[f"{tag}_x1_l{layer}"], rtol=1e-5, atol=1e-6)
         assert (m32 == m64).float().mean() >= 0.99
         np.testing.assert_allclose(s32[0].numpy(), s64[0].numpy(), atol=2e-3)
         assert (g[tag + "_matches0"] >= 0).sum() > 0   # the vectors exercise real matches, not only -1
