@@ -5,15 +5,23 @@ on 1376x376 KITTI-shaped synthetic frames (BASELINE.json metric / configs[1]).
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is ONE call of sship_frontend_batch_device over `--pairs` stereo pairs that are already resident in
-HBM (the reference's unit of work: 1x extract_stereo + 1x device match, src/StereoFrontEnd.cc:14,33).
-Independent pairs shard across ranks with no data-path collective (weak scaling: every rank runs the same
-batch); `value` = all pairs of all ranks / max-over-ranks wall time.
+A step is ONE pass of the hot path over one batch of synthetic input: `--chunks` x `--pairs` stereo pairs that are
+already resident in HBM, processed as `--chunks` calls of sship_frontend_batch_device (the reference's unit of work per
+pair: 1x extract_stereo + 1x device match, src/StereoFrontEnd.cc:14,33).  The default batch (8 x 64 = 512 pairs, every
+chunk different images) makes 20 timed steps last > 2 s.  Independent pairs shard across ranks with no data-path
+collective (weak scaling: every rank runs its own batch); `value` = all pairs of all ranks / max-over-ranks wall time.
 
 Prints ONE JSON line with the driver's fields plus
-  roofline     : the dominant kernel (conv1b: 3x3 64->64 + pool implicit GEMM, 43 % of SuperPoint's FLOPs),
-                 timed live with HIP events on its own stream via sship_sp_bench_layer
-  cpu_baseline : the CPU oracle (kind "port") on this box's host cores, bounded sample, rank 0 at N = 1 only.
+  roofline      : the dominant kernel (conv1a+conv1b+pool, 36 % of the pair's FLOPs), timed live with HIP events on the
+                  stream it runs on (sship_sp_bench_layer)
+  roofline_mfma : the same measurement for every matrix-core stage (conv layers, LightGlue attention / FFN / projections)
+  roofline_hbm  : achieved GB/s against 8 TB/s for the memory-bound stages (NMS tile kernel, convPb, descriptor head /
+                  gather, assignment passes), algorithmic bytes stated per entry
+  n1024         : the same metric with 1024 keypoints per image (the reference engine's upper profile)
+  end_to_end    : the same step with the u8 images uploaded from pinned host memory (double buffered) and keypoints /
+                  matches copied back inside the timed region (PCIe-inclusive; never `value`)
+  cpu_baseline  : the CPU oracle (kind "port") on this box's host cores, bounded sample, rank 0 at N = 1 only.
+--headline-only runs the warm-up and the timed steps and nothing else (profiling passes: every launch is a headline launch).
 """
 import argparse
 import ctypes as C
@@ -103,17 +111,30 @@ def cpu_baseline(spw, lgw, left, right, max_kp, budget_s=20.0):
                       f"C select/gather + fp32 LightGlue, {cores} threads"}
 
 
+def make_chunks(torch, base, chunks):
+    """`chunks` different image sets [2P,H,W] u8 in HBM derived from the P generated pairs: chunk c is the base set rolled
+    vertically by 41 c rows (same roll for left and right: the row-band disparities stay a valid stereo geometry) and
+    intensity-inverted for odd c - every chunk has its own keypoints and matches without 0.1 s of host synthesis per pair."""
+    out = []
+    for c in range(chunks):
+        x = torch.roll(base, shifts=41 * c, dims=1) if c else base
+        out.append((255 - x) if c % 2 else x.clone())
+    return out
+
+
 def main():
     import faulthandler
 
     faulthandler.dump_traceback_later(int(os.environ.get("BENCH_WATCHDOG_S", "900")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step (per GPU), resident in HBM")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per library call (per GPU)")
+    ap.add_argument("--chunks", type=int, default=8, help="library calls per step: a step processes chunks x pairs pairs resident in HBM")
     ap.add_argument("--max-kp", type=int, default=600, help="superpoint.max_keypoints (600 = the KITTI YAML)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="warm-up + timed steps only (profiling passes)")
     args = ap.parse_args()
 
     import numpy as np
@@ -139,6 +160,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     _lib.init(local_rank)
+    L = _lib.lib()
 
     import tempfile
 
@@ -146,7 +168,7 @@ def main():
     spw, lgw = make_superpoint_weights(0), make_lightglue_weights(1)
     save_safetensors(spw, os.path.join(wdir, "sp.safetensors"))
     save_safetensors(lgw, os.path.join(wdir, "lg.safetensors"))
-    P = args.pairs
+    P, CH = args.pairs, args.chunks
     sp = SuperPoint(os.path.join(wdir, "sp.safetensors"), args.max_kp, 0.005, 4, max_batch=2 * P)
     assert sp.initialize(), sp.last_error
     lg = LightGlue(os.path.join(wdir, "lg.safetensors"), W, H, max_keypoints=args.max_kp, max_pairs=P)
@@ -154,12 +176,15 @@ def main():
 
     # synthetic KITTI-shaped pairs (seed 1234 + pair index), uploaded once: inputs are HBM-resident when timing starts
     pairs = [make_stereo_pair(H, W, 1234 + 97 * rank + i) for i in range(P)]
-    imgs = torch.from_numpy(np.stack([im for p in pairs for im in p])).cuda()
+    base = torch.from_numpy(np.stack([im for p in pairs for im in p])).cuda()
+    chunks = make_chunks(torch, base, CH)
     fe = FrontEndBatch(sp, lg, P, H, W)
+    # every library call of the bench goes on ONE stream: torch's current stream (the legacy default stream, handle 0)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        fe.run(imgs, stream)
+        for x in chunks:
+            fe.run(x, stream)
 
     for _ in range(args.warmup):
         step()
@@ -182,111 +207,278 @@ def main():
 
     n_kp = fe.n.cpu().numpy()
     n_match = int((fe.matches0.cpu().numpy() >= 0).sum())
-    total_pairs = world * P * args.steps
+    total_pairs = world * P * CH * args.steps
     value = total_pairs / dt
+    flops_pair = 2 * sp_flops_per_image(H, W) + lg_flops_per_pair(args.max_kp)
 
-    out = None
     if rank == 0:
-        # ---- per-stage device time (hipEvents inside the library), single profiled step ----
-        _lib.lib().sship_set_profiling(1)
-        step(); torch.cuda.synchronize()
-        stages = {k: round(v, 4) for k, v in _lib.stage_timings().items()}
-        _lib.lib().sship_set_profiling(0)
-        # ---- roofline of the dominant kernel: conv1b = igemm<3x3, 64->64, +pool> over 2P images ----
-        ms = C.c_float(0)
-        macs = C.c_double(0)
-        _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, 1, 2 * P, H, W, 20, C.byref(ms), C.byref(macs)))
-        ach = 2.0 * macs.value / (ms.value * 1e-3) / 1e12
-        layer_ms = {}
-        # layer 0 / 11 are stand-alone reference kernels that are NOT on the extraction path (conv1a is fused into
-        # conv1b's staging, convDb runs only at the selected keypoints inside k_desc_head_gather)
-        for lid, name in enumerate(["conv1a_standalone_offpath", "conv1a+conv1b+pool", "conv2a", "conv2b+pool", "conv3a",
-                                    "conv3b+pool", "conv4a", "conv4b", "convPa", "convPb", "convDa_dense_offpath", "convDb_dense_offpath"]):
-            m2 = C.c_float(0)
-            _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, lid, 2 * P, H, W, 10, C.byref(m2), None))
-            layer_ms[name] = round(m2.value, 4)
-        # HBM bytes per launch from the PMC passes of scripts/pmc_traffic.sh (same command, same batch); null if the
-        # committed summary was taken at another batch size
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_conv1ab.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                if pj.get("pairs_per_step") == P:
-                    traffic = pj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        alg_bytes = 2 * P * (H * W + (H // 2) * (W // 2) * 64 * 2)   # u8 image in, pooled fp16 64-ch map out
-        # what the matrix pipe sustains on THIS box under its power budget (pure register-resident MFMA stream):
-        # zero operands run at the datasheet rate, random ones about a third lower - context for `frac`
-        probe = {}
-        for name, rnd in (("zero_operands", 0), ("random_operands", 1)):
-            tf = C.c_float(0)
-            _lib.check(_lib.lib().sship_mfma_probe(rnd, C.byref(tf)))
-            probe[name] = round(tf.value, 1)
-        roofline = {"kernel": "conv3x3_pp<64,64,pool,fuse1a> (conv1a+conv1b+maxpool, 36 % of the pair's FLOPs)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "launch_ms": round(ms.value, 4), "flops_per_launch": 2.0 * macs.value,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "sustained_mfma_probe_tflops": probe,
-                    "frac_of_sustained_random_probe": round(ach / probe["random_operands"], 4) if probe["random_operands"] > 0 else None}
-        flops_pair = 2 * sp_flops_per_image(H, W) + lg_flops_per_pair(args.max_kp)
         out = {
             "metric": "stereo pairs/sec (SPx2+LG) at 1376x376", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: SuperPoint x2 + select + gather + 1x LightGlue on 1376x376 stereo pairs, "
-                                   f"{P} pairs per step per GPU resident in HBM, max_keypoints {args.max_kp}, seeded synthetic weights",
-                       "pairs_per_step": P, "max_keypoints": args.max_kp, "image": [H, W],
-                       "keypoints_found": [int(n_kp.min()), int(n_kp.max())], "matches_last_step": n_match,
+            "config": {"workload": f"configs[1]: SuperPoint x2 + select + gather + 1x LightGlue on 1376x376 stereo pairs; a step = "
+                                   f"{CH} x {P} = {CH * P} pairs per GPU resident in HBM ({CH} library calls of {P} pairs, different images per "
+                                   f"call), max_keypoints {args.max_kp}, seeded synthetic weights",
+                       "pairs_per_step": P * CH, "pairs_per_call": P, "calls_per_step": CH, "max_keypoints": args.max_kp, "image": [H, W],
+                       "keypoints_found": [int(n_kp.min()), int(n_kp.max())], "matches_last_call": n_match,
+                       "timed_seconds": round(dt, 3),
                        "parallelism": f"replicated weights, pairs sharded over {world} rank(s), no data-path collective"},
             "algorithmic_gflop_per_pair": round(flops_pair / 1e9, 2),
             "effective_tflops": round(value * flops_pair / 1e12, 2),
-            "stage_ms": stages, "layer_ms": layer_ms,
-            "roofline": roofline,
         }
-        # single-pair latency (the reference's per-frame unit): P = 1 through the same fused call
-        fe1 = FrontEndBatch(sp, lg, 1, H, W)
-        for _ in range(5):
-            fe1.run(imgs[:2], stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(50):
-            fe1.run(imgs[:2], stream)
-        torch.cuda.synchronize()
-        out["latency_ms_single_pair"] = round((time.perf_counter() - t1) / 50 * 1e3, 4)
-        # the unit the reference actually runs per frame: the stereo match PLUS a second LightGlue call
-        # against the previous keyframe (VoEstimator.cc:243).  Emulated with left(p) vs left(p+1) on the features of
-        # the step itself; reported next to the headline metric, not instead of it.
-        idx = torch.arange(2 * P, device="cuda").view(P, 2)
-        idx[:, 1] = (idx[:, 0] + 2) % (2 * P)      # set 0 = left of pair p, set 1 = left of pair p + 1
-        idx = idx.reshape(-1)
-        m2 = torch.empty((P, args.max_kp), dtype=torch.int32, device="cuda")
-        s2 = torch.empty((P, args.max_kp), dtype=torch.float32, device="cuda")
-
-        def deployed_step():
-            fe.run(imgs, stream)
-            lg.match_batch_device(fe.kp.index_select(0, idx), fe.n.index_select(0, idx), fe.desc.index_select(0, idx), m2, s2, stream)
-
-        for _ in range(2):
-            deployed_step()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(10):
-            deployed_step()
-        torch.cuda.synchronize()
-        out["deployed_unit"] = {"pairs_per_s": round(P * 10 / (time.perf_counter() - t2), 2),
-                                "unit": "SuperPoint x2 + LightGlue(L,R) + LightGlue(L, previous keyframe L) per pair",
-                                "keyframe_matches_last_step": int((m2 >= 0).sum().item())}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], args.max_kp)
+        if not args.headline_only:
+            extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, world, spw, lgw, pairs)
         print(json.dumps(out), flush=True)
     sp.close(); lg.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, world, spw, lgw, pairs):
+    """Everything next to the headline number (rank 0): per-stage times, rooflines, N = 1024, PCIe-inclusive variant, latency,
+    the deployed unit, CPU baseline.  All after the timed region."""
+    from superslam_amd import FrontEndBatch, LightGlue, SuperPoint, _lib
+
+    P, CH, K = args.pairs, args.chunks, args.max_kp
+    Hc, Wc = H // 8, W // 8
+    B = 2 * P
+
+    # ---- step-time distribution: 40 calls, events between calls on the launch stream, no host synchronisation ----
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+    ev[0].record()
+    for i in range(40):
+        fe.run(chunks[i % CH], stream)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    call_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(40))
+    out["call_ms"] = {"calls": 40, "pairs_per_call": P, "median": round(call_ms[20], 4), "p95": round(call_ms[37], 4),
+                      "min": round(call_ms[0], 4), "max": round(call_ms[-1], 4)}
+
+    # ---- per-stage device time (hipEvents inside the library), one profiled call ----
+    L.sship_set_profiling(1)
+    fe.run(chunks[0], stream); torch.cuda.synchronize()
+    stages = {k: round(v, 4) for k, v in _lib.stage_timings().items()}
+    L.sship_set_profiling(0)
+    scopes = {}
+    for k, v in stages.items():   # the reference's own SUPERSLAM_PROFILE labels = sums over this library's finer stages
+        scopes[k.split(":")[0]] = round(scopes.get(k.split(":")[0], 0.0) + v, 4)
+    scopes["fe_extract_stereo"] = round(scopes.get("sp_gpu_infer", 0.0) + scopes.get("sp_extract_stereo", 0.0), 4)
+    out["stage_ms"] = stages
+    out["reference_scope_ms"] = scopes
+
+    # ---- matrix-core stages: launch time by HIP events on the kernel's own stream -> TFLOP/s vs the dense fp16 peak ----
+    def sp_layer(lid, iters=10):
+        ms, macs = C.c_float(0), C.c_double(0)
+        _lib.check(L.sship_sp_bench_layer(sp._h, lid, B, H, W, iters, C.byref(ms), C.byref(macs)))
+        return ms.value, macs.value
+
+    def lg_stage(sid, iters=10):
+        ms = C.c_float(0)
+        _lib.check(L.sship_lg_bench_stage(lg._h, sid, iters, C.byref(ms)))
+        return ms.value
+
+    ms1, macs1 = sp_layer(1, 20)
+    ach = 2.0 * macs1 / (ms1 * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_conv1ab.json")
+    if os.path.exists(pmc):
+        try:
+            pj = json.load(open(pmc))
+            if pj.get("pairs_per_call", pj.get("pairs_per_step")) == P and pj.get("headline_launches_only"):
+                traffic = pj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    alg_bytes = B * (H * W + (H // 2) * (W // 2) * 64 * 2)   # u8 image in, pooled fp16 64-ch map out
+    probe = {}
+    for name, rnd in (("zero_operands", 0), ("random_operands", 1)):
+        tf = C.c_float(0)
+        _lib.check(L.sship_mfma_probe(rnd, C.byref(tf)))
+        probe[name] = round(tf.value, 1)
+    out["roofline"] = {"kernel": "conv3x3_pp<64,64,pool,fuse1a> (conv1a+conv1b+maxpool, 36 % of the pair's FLOPs)", "bound": "mfma",
+                       "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                       "launch_ms": round(ms1, 4), "flops_per_launch": 2.0 * macs1, "images_per_launch": B,
+                       "algorithmic_bytes_per_launch": alg_bytes,
+                       "sustained_mfma_probe_tflops": probe,
+                       "frac_of_sustained_random_probe": round(ach / probe["random_operands"], 4) if probe["random_operands"] > 0 else None}
+    mfma = []
+    names = ["conv1a_standalone_offpath", "conv1a+conv1b+pool", "conv2a", "conv2b+pool", "conv3a", "conv3b+pool", "conv4a", "conv4b",
+             "convPa", "convPb", "convDa_dense_offpath", "convDb_dense_offpath"]
+    layer_ms = {}
+    for lid, name in enumerate(names):
+        ms, macs = sp_layer(lid)
+        layer_ms[name] = round(ms, 4)
+        if "offpath" not in name and lid != 9:
+            tf = 2.0 * macs / (ms * 1e-3) / 1e12
+            mfma.append({"kernel": name, "launch_ms": round(ms, 4), "gflop_per_launch": round(2.0 * macs / 1e9, 2),
+                         "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)})
+    out["layer_ms"] = layer_ms
+    # LightGlue stages over the state of the last call (P pairs, S = 2P sequences of n keypoints each; FLOPs for n = max_kp)
+    n, S = K, 2 * P
+    lg_flops = {
+        "lg_wqkv0_proj": 2.0 * S * n * 768 * 256,
+        "lg_self_attention": 2.0 * S * 4 * n * n * 64 * 2,
+        "lg_cross_attention": 2.0 * S * 4 * n * n * 64 * 2,
+        "lg_self_ffn+to_qk|to_v": 2.0 * S * n * (512 * 512 + 512 * 256 + 256 * 256 + 512 * 256),
+        "lg_cross_ffn+wqkv": 2.0 * S * n * (512 * 512 + 512 * 256 + 256 * 256 + 768 * 256),
+        "lg_last_ffn+final_proj": 2.0 * S * n * (512 * 512 + 512 * 256 + 256 * 256 + 256 * 256 + 256),
+        "lg_assign_sim": 2.0 * P * n * n * 256,
+    }
+    lg_ms = {}
+    for sid, name in enumerate(lg_flops):
+        ms = lg_stage(sid)
+        lg_ms[name] = round(ms, 4)
+        tf = lg_flops[name] / (ms * 1e-3) / 1e12
+        mfma.append({"kernel": name, "launch_ms": round(ms, 4), "gflop_per_launch": round(lg_flops[name] / 1e9, 2),
+                     "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                     "note": "out_proj / to_out are folded into ffn.0 on the host: their FLOPs are counted (algorithmic), not executed"
+                     if "ffn" in name else None})
+    out["roofline_mfma"] = mfma
+    lg_layers_ms = stages.get("fe_lg_stereo_match:layers_x9", 0.0)
+    lg_total_ms = sum(v for k, v in stages.items() if k.startswith("fe_lg_stereo_match"))
+    if lg_total_ms > 0:
+        out["lightglue_mfma"] = {"gflop_per_call": round(P * lg_flops_per_pair(K) / 1e9, 1), "ms_per_call": round(lg_total_ms, 4),
+                                 "layers_x9_ms": round(lg_layers_ms, 4),
+                                 "achieved": round(P * lg_flops_per_pair(K) / (lg_total_ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                                 "frac": round(P * lg_flops_per_pair(K) / (lg_total_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+
+    # ---- memory-bound stages: algorithmic bytes / launch time vs 8 TB/s ----
+    n_cand_bytes = 8.0 * 7000  # ~7 k candidates x 8 B per image (data dependent; DESIGN.md)
+    hbm = []
+
+    def hbm_entry(kernel, ms, alg_bytes, what, impl_bytes=None):
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        e = {"kernel": kernel, "bound": "hbm", "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes": what}
+        if impl_bytes is not None:
+            e["implementation_bytes_per_launch"] = int(impl_bytes)
+        hbm.append(e)
+
+    ms_nms, _ = sp_layer(12)
+    hbm_entry("k_nms_tile (softmax + depth-to-space + 9x9 NMS + threshold + compaction)", ms_nms,
+              B * (65 * Hc * Wc * 4 + n_cand_bytes), "fp32 logits [65,Hc,Wc] read once + ~7k candidates x 8 B written, per image",
+              B * (80 * Hc * Wc * 4 + n_cand_bytes))
+    ms_pb = layer_ms["convPb"]
+    hbm_entry("igemm convPb (1x1, 256 -> 65, fp32 logits)", ms_pb, B * (256 * Hc * Wc * 2 + 65 * Hc * Wc * 4),
+              "fp16 convPa map read + fp32 logits written, per image", B * (256 * Hc * Wc * 2 + 80 * Hc * Wc * 4))
+    ms_topk, _ = sp_layer(13)
+    hbm_entry("k_topk (radix select + bitonic sort + keypoints/cells)", ms_topk, B * (n_cand_bytes + K * 20),
+              "candidates read once + kp/cells written (latency-bound: one workgroup per image)")
+    ms_dh, _ = sp_layer(14)
+    hbm_entry("k_desc_head_sparse (convDa + convDb at the keypoints + normalise x2 + gather)", ms_dh,
+              B * (K * 9 * 128 * 2 + K * 256 * 2 + 8 * K), "9 x 256 B encoder rows per keypoint read + [N,256] fp16 written + 8N index bytes, "
+              "per image (SURVEY 8(d) gather figure is the last two terms: N*256*2 read + write + 8N)")
+    ms_as = lg_stage(7)
+    hbm_entry("k_assign_* (row/col log-sum-exp, row/col arg-max, filter)", ms_as, P * (2 * n * n * 4 + 4 * n * 4),
+              "fp32 sim [n,n] read twice (one statistics pass, one arg-max pass is the algorithmic minimum) per pair",
+              P * (4 * n * n * 4))
+    out["roofline_hbm"] = hbm
+
+    # ---- N = 1024 keypoints per image (the reference engine's upper profile; SURVEY 8(d) config 2 second run) ----
+    K2 = 1024
+    sp2 = SuperPoint(os.path.join(wdir, "sp.safetensors"), K2, 0.005, 4, max_batch=B)
+    lg2 = LightGlue(os.path.join(wdir, "lg.safetensors"), W, H, max_keypoints=K2, max_pairs=P)
+    assert sp2.initialize() and lg2.initialize()
+    fe2 = FrontEndBatch(sp2, lg2, P, H, W)
+    for x in chunks[:2]:
+        fe2.run(x, stream)
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for x in chunks:
+            fe2.run(x, stream)
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t0
+    n2 = fe2.n.cpu().numpy()
+    fp2 = 2 * sp_flops_per_image(H, W) + lg_flops_per_pair(K2)
+    out["n1024"] = {"value": round(reps * CH * P / dt2, 2), "unit": "pairs/s", "max_keypoints": K2,
+                    "keypoints_found": [int(n2.min()), int(n2.max())], "pairs_timed": reps * CH * P, "timed_seconds": round(dt2, 3),
+                    "algorithmic_gflop_per_pair": round(fp2 / 1e9, 2), "effective_tflops": round(reps * CH * P / dt2 * fp2 / 1e12, 2),
+                    "matches_last_call": int((fe2.matches0 >= 0).sum().item())}
+    sp2.close(); lg2.close()
+
+    # ---- PCIe-inclusive variant: u8 images from pinned host memory (double buffered on a copy stream), keypoints / counts /
+    # matches / scores copied back to pinned memory, all inside the timed region.  Descriptors stay on the device, as in
+    # the reference (pool slots, DescriptorPool.h). ----
+    host_in = [x.cpu().pin_memory() for x in chunks]
+    dev_in = [torch.empty_like(chunks[0]) for _ in range(2)]
+    h_kp = torch.empty((B, K, 3), dtype=torch.float32).pin_memory()
+    h_n = torch.empty((B,), dtype=torch.int32).pin_memory()
+    h_m = torch.empty((P, K), dtype=torch.int32).pin_memory()
+    h_s = torch.empty((P, K), dtype=torch.float32).pin_memory()
+    copy_s = torch.cuda.Stream()
+    main_s = torch.cuda.current_stream()
+    up = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+
+    def e2e_pass(reps):
+        with torch.cuda.stream(copy_s):
+            dev_in[0].copy_(host_in[0], non_blocking=True); up[0].record(copy_s)
+        for i in range(reps * CH):
+            b = i & 1
+            if i + 1 < reps * CH:
+                with torch.cuda.stream(copy_s):
+                    copy_s.wait_event(done[b ^ 1]) if i >= 1 else None   # the buffer's previous consumer has finished
+                    dev_in[b ^ 1].copy_(host_in[(i + 1) % CH], non_blocking=True); up[b ^ 1].record(copy_s)
+            main_s.wait_event(up[b])
+            fe.run(dev_in[b], stream)
+            done[b].record(main_s)
+            h_kp.copy_(fe.kp, non_blocking=True); h_n.copy_(fe.n, non_blocking=True)
+            h_m.copy_(fe.matches0, non_blocking=True); h_s.copy_(fe.mscores0, non_blocking=True)
+        torch.cuda.synchronize()
+
+    e2e_pass(1)
+    reps = 4
+    t0 = time.perf_counter()
+    e2e_pass(reps)
+    dte = time.perf_counter() - t0
+    h2d = reps * CH * B * H * W
+    d2h = reps * CH * (B * K * 12 + B * 4 + P * K * 8)
+    out["end_to_end"] = {"value": round(reps * CH * P / dte, 2), "unit": "pairs/s", "pairs_timed": reps * CH * P, "timed_seconds": round(dte, 3),
+                         "includes": "pinned u8 H2D (double buffered, copy stream) + fused step + D2H of keypoints, counts, matches0, mscores0",
+                         "h2d_bytes_per_pair": 2 * H * W, "d2h_bytes_per_pair": int(d2h / (reps * CH * P)),
+                         "h2d_gb_per_s": round(h2d / dte / 1e9, 2), "matches_last_call": int((h_m >= 0).sum().item())}
+
+    # ---- single-pair latency (the reference's per-frame unit): P = 1 through the same fused call ----
+    fe1 = FrontEndBatch(sp, lg, 1, H, W)
+    for _ in range(5):
+        fe1.run(base[:2], stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(50):
+        fe1.run(base[:2], stream)
+    torch.cuda.synchronize()
+    out["latency_ms_single_pair"] = round((time.perf_counter() - t1) / 50 * 1e3, 4)
+
+    # ---- the unit the reference actually runs per frame (SURVEY 8(d)): the stereo match PLUS a second LightGlue call
+    # against the previous keyframe (VoEstimator.cc:243).  Emulated with left(p) vs left(p+1) on the features of the call
+    # itself; both LightGlue calls and the extractor are on the same stream.  Reported next to the headline, not instead. ----
+    idx = torch.arange(2 * P, device="cuda").view(P, 2)
+    idx[:, 1] = (idx[:, 0] + 2) % (2 * P)      # set 0 = left of pair p, set 1 = left of pair p + 1
+    idx = idx.reshape(-1)
+    m2 = torch.empty((P, K), dtype=torch.int32, device="cuda")
+    s2 = torch.empty((P, K), dtype=torch.float32, device="cuda")
+
+    def deployed_call(x):
+        fe.run(x, stream)
+        lg.match_batch_device(fe.kp.index_select(0, idx), fe.n.index_select(0, idx), fe.desc.index_select(0, idx), m2, s2, stream)
+
+    for x in chunks[:2]:
+        deployed_call(x)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(3):
+        for x in chunks:
+            deployed_call(x)
+    torch.cuda.synchronize()
+    out["deployed_unit"] = {"pairs_per_s": round(3 * CH * P / (time.perf_counter() - t2), 2),
+                            "unit": "SuperPoint x2 + LightGlue(L,R) + LightGlue(L, previous keyframe L) per pair",
+                            "keyframe_matches_last_call": int((m2 >= 0).sum().item())}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], K)
 
 
 if __name__ == "__main__":

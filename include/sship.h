@@ -10,7 +10,10 @@
  *   - every function returns an int status (0 = SSHIP_OK); nothing throws or longjmps across the ABI;
  *     sship_last_error() returns a thread-local message for the last non-zero status;
  *   - "_dev" pointers are HIP device pointers, all others host pointers;
- *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream);
+ *   - `stream` is a hipStream_t passed as void*; NULL is the legacy default stream itself (= torch's default
+ *     stream), so consecutive asynchronous calls made with NULL - extractor then matcher - are ordered with each
+ *     other and with the caller's default-stream work.  The synchronous host-image / host-keypoint entry points
+ *     use the handle's own (blocking) stream and return after synchronising it;
  *   - external dtypes follow the reference engines (scripts/rebuild_engines.sh:85-92,108-115):
  *     image u8 (normalised to [0,1] on device), scores f32, descriptors f16, kpts f32,
  *     matches0 i32, mscores0 f32.  Internal accumulation is f32.
@@ -57,7 +60,14 @@ int sship_device_synchronize(void);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sship_pool sship_pool;
 int sship_pool_create(int num_slots, int max_keypoints, int dim, sship_pool** out);
+/* Frees the device slots and drops the creator's reference.  The bookkeeping (free-list, mutex) is reference counted
+ * like the reference's shared_ptr<FreeList> (DescriptorPool.h:71-75): every DeviceDescriptors handle holds one
+ * reference (sship_pool_retain when the handle is made, sship_pool_release + sship_pool_release_ref in its deleter),
+ * so a handle may outlive the pool's owner; its data pointer then dangles exactly as in the reference
+ * (DescriptorPool.cc:27-32) but releasing it is safe. */
 void sship_pool_destroy(sship_pool* pool);
+void sship_pool_retain(sship_pool* pool);
+void sship_pool_release_ref(sship_pool* pool);
 int sship_pool_acquire(sship_pool* pool);            /* FreeList::acquire: slot index or -1 when exhausted */
 void sship_pool_release(sship_pool* pool, int slot); /* FreeList::release */
 int sship_pool_in_use(const sship_pool* pool);       /* FreeList::in_use */
@@ -185,6 +195,18 @@ int sship_lg_match_host(sship_lg* lg, const float* kp0, int kp_stride0, int n0, 
  * [pairs, max_kp]; rows >= n are -1 / 0. */
 int sship_lg_match_batch_device(sship_lg* lg, const float* kp_dev, const int* n_dev, const void* desc_dev,
                                 int pairs, int32_t* matches0_dev, float* mscores0_dev, void* stream);
+/* Test-only introspection of the matcher (no reference counterpart; used by the parity suite to compare the internals
+ * with the oracle layer by layer - the product never calls these).
+ * sship_lg_debug_set_layers: the next match calls on this handle run only the first n_layers (1..9) transformer layers and
+ *   skip the assignment (matches0 = -1, mscores0 = 0); 9 restores the full matcher.
+ * sship_lg_debug_read: after a match call, copy state of this handle to the host as f32 (device-synchronising):
+ *   SSHIP_LG_DEBUG_X    residual stream of sequence `index` (2p = set 0, 2p+1 = set 1 of pair p): out[rows][256]
+ *   SSHIP_LG_DEBUG_SIM  assignment similarity md0 md1^T of pair `index`: out[rows][cols]
+ *   SSHIP_LG_DEBUG_KPTS normalised keypoints of sequence `index` (src/LightGlue.cc:241-251 on the device): out[rows][2]
+ *   SSHIP_LG_DEBUG_ROPE rotary table of sequence `index`: out[rows][64] = 32 (cos, sin) pairs */
+enum { SSHIP_LG_DEBUG_X = 0, SSHIP_LG_DEBUG_SIM = 1, SSHIP_LG_DEBUG_KPTS = 2, SSHIP_LG_DEBUG_ROPE = 3 };
+int sship_lg_debug_set_layers(sship_lg* lg, int n_layers);
+int sship_lg_debug_read(sship_lg* lg, int what, int index, int rows, int cols, float* out);
 /* Match post-processing, src/LightGlue.cc:326-363: ascending i, skip -1, distance = 1 - score.
  * Returns the number of matches (>= 0). */
 int sship_filter_matches(const int32_t* matches0, const float* mscores0, int n0, int* query_idx,
@@ -202,9 +224,12 @@ int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs_
                                 void* desc_out_dev, float* kp_out_dev, int* n_out_dev,
                                 int32_t* matches0_dev, float* mscores0_dev, void* stream);
 
-/* Per-stage device timings (ms) of the last *_batch_device call made with profiling enabled
- * (sship_set_profiling(1) inserts hipEvents; off by default).  Labels follow the reference's profile
- * scopes (src/SuperPoint.cc:639,904; src/StereoFrontEnd.cc:13,32).  Returns the number of stages. */
+/* Per-stage device timings (ms) of the calling thread's last call sequence made with profiling enabled
+ * (sship_set_profiling(1) inserts hipEvents; off by default).  Labels are "<scope>:<stage>" where <scope> is the
+ * reference's own SUPERSLAM_PROFILE label the stage belongs to - sp_gpu_infer (src/SuperPoint.cc:639),
+ * sp_extract_stereo (:904), fe_lg_stereo_match (src/StereoFrontEnd.cc:32) - and <stage> this library's finer split
+ * (encoder, heads, select, gather, posenc_qkv0, layers_x9, assign_filter); summing a scope's stages gives the
+ * reference's figure.  Timers are per thread.  Returns the number of stages. */
 void sship_set_profiling(int on);
 int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
 
@@ -214,6 +239,14 @@ int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
  * 2 conv2a, 3 conv2b (+pool), 4 conv3a, 5 conv3b (+pool), 6 conv4a, 7 conv4b, 8 convPa, 9 convPb, 10 convDa,
  * 11 convDb.  *macs receives the layer's multiply-accumulate count for that shape. */
 int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms, double* macs);
+/* (layer ids 12-14 are the memory-bound stages of the same handle: 12 = softmax + depth-to-space + NMS + threshold +
+ * candidate compaction, 13 = top-k, 14 = descriptor head at the selected keypoints; *macs = 0 for them.)
+ *
+ * Same for one stage of the matcher, over the state the last match call left on this handle, timed with hipEvents on the
+ * handle's stream: 0 first Wqkv projection, 1 self attention, 2 cross attention (both directions), 3 SelfBlock FFN + the
+ * fused [to_qk|to_v] projection, 4 CrossBlock FFN + the fused next Wqkv, 5 last CrossBlock FFN + final_proj + matchability,
+ * 6 assignment similarity, 7 double log-softmax + mutual arg-max + filter (five kernels). */
+int sship_lg_bench_stage(sship_lg* lg, int stage, int iters, float* avg_ms);
 
 /* Measurement aid for the roofline line: the v_mfma_f32_32x32x16_f16 rate (TFLOP/s) the device sustains from registers
  * for ~5 ms on every CU, with zero (random_operands = 0) or random fp16 operands.  The chip clocks to its power budget,

@@ -67,12 +67,18 @@ private:
   std::vector<int> free_slots_;
 };
 
-// Pool handle shared by every DeviceDescriptors copy, so a handle may outlive the extractor object without
-// its deleter touching freed bookkeeping (DescriptorPool.h:71-75).  Device memory still dies with the pool.
+// Pool handle shared by every DeviceDescriptors copy.  It holds its own REFERENCE on the C-side bookkeeping
+// (sship_pool_retain), so a handle may outlive the extractor object - whose sship_sp_destroy frees the device slots and
+// drops only the extractor's reference - without its deleter touching freed memory (DescriptorPool.h:71-75: the
+// deleter captures the shared FreeList, not `this`).  Device memory still dies with the pool (DescriptorPool.cc:27-32).
 struct PoolRef {
   sship_pool* pool = nullptr;
-  bool owned = false;
-  ~PoolRef() { if (owned && pool) sship_pool_destroy(pool); }
+  bool owned = false;   // this object created the pool (stand-alone DescriptorPool): it also frees the device slots
+  ~PoolRef() {
+    if (!pool) return;
+    if (owned) sship_pool_destroy(pool);   // frees the slots, drops the creator's reference
+    else sship_pool_release_ref(pool);     // borrowed from an extractor: drop the reference taken in the constructor
+  }
 };
 
 class DescriptorPool {
@@ -81,7 +87,10 @@ public:
     if (sship_pool_create(num_slots, max_keypoints, dim, &ref_->pool) == SSHIP_OK) ref_->owned = true;
   }
   explicit DescriptorPool(sship_pool* borrowed, int max_keypoints, int dim)
-      : ref_(std::make_shared<PoolRef>()), dim_(dim), max_kp_(max_keypoints) { ref_->pool = borrowed; }
+      : ref_(std::make_shared<PoolRef>()), dim_(dim), max_kp_(max_keypoints) {
+    ref_->pool = borrowed;
+    sship_pool_retain(borrowed);
+  }
   DescriptorPool(const DescriptorPool&) = delete;
   DescriptorPool& operator=(const DescriptorPool&) = delete;
 

@@ -98,3 +98,14 @@ def float_to_half(f: np.ndarray) -> np.ndarray:
     out = np.empty(a.shape, np.uint16)
     lib().orc_float_to_half(_p(a), _p(out), C.c_long(a.size))
     return out.view(np.float16)
+
+
+def bgr2gray_u8(img_bgr: np.ndarray) -> np.ndarray:
+    """cv::cvtColor(img, gray, cv::COLOR_BGR2GRAY) on CV_8UC3 (call sites src/SuperPoint.cc:388,771).
+
+    OpenCV itself is a third-party dependency absent from this image; its published 8-bit algorithm (imgproc
+    color_rgb.simd.hpp, RGB2Gray<uchar>, stable across 3.x / 4.x) is fixed point with a 14-bit shift:
+      gray = (B*1868 + G*9617 + R*4899 + (1 << 13)) >> 14      (0.114, 0.587, 0.299 scaled by 2^14 and rounded)
+    """
+    a = np.ascontiguousarray(img_bgr, np.uint8).astype(np.int64)
+    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)

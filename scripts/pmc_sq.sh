@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 : > $R/$OUT
 pass() {  # name, counters...
   local n=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_sq -o sq_$n -- python $R/bench.py --steps 2 --warmup 1 --pairs $P --no-cpu-baseline > /tmp/pmc_sq/run_$n.log 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_sq -o sq_$n -- python $R/bench.py --headline-only --steps 2 --warmup 1 --chunks 2 --pairs $P > /tmp/pmc_sq/run_$n.log 2>&1
   if [ -f /tmp/pmc_sq/sq_${n}_results.db ]; then python $R/scripts/rocpd_pmc.py /tmp/pmc_sq/sq_${n}_results.db >> $R/$OUT; else echo "pass $n failed:" >> $R/$OUT; tail -5 /tmp/pmc_sq/run_$n.log >> $R/$OUT; fi
 }
 pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES

@@ -41,6 +41,8 @@ _SIGS = {
     "sship_device_synchronize": (ip, []),
     "sship_pool_create": (ip, [ip, ip, ip, C.POINTER(vp)]),
     "sship_pool_destroy": (None, [vp]),
+    "sship_pool_retain": (None, [vp]),
+    "sship_pool_release_ref": (None, [vp]),
     "sship_pool_acquire": (ip, [vp]),
     "sship_pool_release": (None, [vp, ip]),
     "sship_pool_in_use": (ip, [vp]),
@@ -67,10 +69,13 @@ _SIGS = {
     "sship_lg_match_device": (ip, [vp, vp, ip, ip, vp, vp, ip, ip, vp, vp, vp]),
     "sship_lg_match_host": (ip, [vp, vp, ip, ip, vp, vp, ip, ip, vp, vp, vp]),
     "sship_lg_match_batch_device": (ip, [vp, vp, vp, vp, ip, vp, vp, vp]),
+    "sship_lg_debug_set_layers": (ip, [vp, ip]),
+    "sship_lg_debug_read": (ip, [vp, ip, ip, ip, ip, vp]),
     "sship_filter_matches": (ip, [vp, vp, ip, vp, vp, vp]),
     "sship_desc_to_host": (ip, [vp, ip, ip, vp]),
     "sship_frontend_batch_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp, vp]),
     "sship_sp_bench_layer": (ip, [vp, ip, ip, ip, ip, ip, C.POINTER(fp), C.POINTER(C.c_double)]),
+    "sship_lg_bench_stage": (ip, [vp, ip, ip, C.POINTER(fp)]),
     "sship_mfma_probe": (ip, [ip, C.POINTER(fp)]),
     "sship_set_profiling": (None, [ip]),
     "sship_get_stage_timings": (ip, [C.POINTER(C.c_char_p), C.POINTER(fp), ip]),

@@ -1,6 +1,7 @@
 // C ABI of libsuperslam_hip.so (include/sship.h): weights, workspaces, streams and the launch sequences of
 // the SuperPoint extractor, the LightGlue matcher and the fused front-end step.  gfx950 only; there is no CPU
 // fallback anywhere in this library - without a GPU every entry point fails with SSHIP_ERR_NO_DEVICE.
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -233,10 +234,20 @@ static int upload_conv(const float* w, const float* bias, int cout, int cin, int
     const int src = row_map ? (*row_map)[co] : co;
     bp[co] = bias ? bias[src] * (row_scale ? (*row_scale)[co] : 1.f) : 0.f;
   }
-  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.w), pk.size() * sizeof(_Float16)));
-  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.bias), bp.size() * sizeof(float)));
-  SSHIP_HIP_CHECK(hipMemcpy(out.w, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-  SSHIP_HIP_CHECK(hipMemcpy(out.bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  // a failure part-way leaves nothing behind (the caller's error path only frees what `out` still points to)
+  auto fail_free = [&](hipError_t e, const char* what) {
+    if (out.w) (void)hipFree(out.w);
+    if (out.bias) (void)hipFree(out.bias);
+    out.w = nullptr; out.bias = nullptr;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return (int)SSHIP_ERR_HIP;
+  };
+  out.w = nullptr; out.bias = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&out.w), pk.size() * sizeof(_Float16))) != hipSuccess) return fail_free(e, "upload_conv: hipMalloc(weights)");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&out.bias), bp.size() * sizeof(float))) != hipSuccess) return fail_free(e, "upload_conv: hipMalloc(bias)");
+  if ((e = hipMemcpy(out.w, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice)) != hipSuccess) return fail_free(e, "upload_conv: hipMemcpy(weights)");
+  if ((e = hipMemcpy(out.bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail_free(e, "upload_conv: hipMemcpy(bias)");
   out.cin = cin; out.cout = cout; out.cout_pad = cout_pad; out.ks = ks; out.ct = ct;
   return SSHIP_OK;
 }
@@ -246,33 +257,49 @@ static void free_conv(ConvW& c) {
   c.w = nullptr; c.bias = nullptr;
 }
 static int upload_floats(const float* src, size_t n, float** dst) {
+  *dst = nullptr;
   SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(float)));
-  SSHIP_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+  if (hipError_t e = hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice)) {
+    (void)hipFree(*dst); *dst = nullptr;
+    set_error(std::string("upload_floats: ") + hipGetErrorString(e));
+    return SSHIP_ERR_HIP;
+  }
   return SSHIP_OK;
 }
 
-static bool g_inited = false;
-static int g_device = -1;  // the device sship_init selected; every API entry binds the calling thread to it
+static std::atomic<bool> g_inited{false};
+static std::atomic<int> g_device{-1};  // the device sship_init selected; every API entry binds the calling thread to it
+static std::mutex g_init_mu;           // sship_init may race between the tracking and the loop-closure thread
 // HIP's current device is per thread and defaults to 0: a second caller thread (the reference's loop-closure worker,
 // SuperSLAM.cc:129-133) on a rank that owns device != 0 would otherwise launch on the wrong GPU.
 static inline void bind_thread() {
   static thread_local bool bound = false;
-  if (!bound && g_device >= 0) { (void)hipSetDevice(g_device); bound = true; }
+  const int dev = g_device.load(std::memory_order_acquire);
+  if (!bound && dev >= 0) { (void)hipSetDevice(dev); bound = true; }
 }
 static int require_device() {
-  if (g_inited) return SSHIP_OK;
+  if (g_inited.load(std::memory_order_acquire)) return SSHIP_OK;
   return sship_init(-1);
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage timers (off by default)
 // ------------------------------------------------------------------------------------------------
+// One timer per calling THREAD (thread_local): the tracking thread and the loop-closure thread each own a handle
+//  and may both have profiling on; sship_get_stage_timings reports the calling thread's last sequence.
+// Labels are "<reference profile scope>:<stage>" - the scopes are the reference's own SUPERSLAM_PROFILE labels
+// (sp_gpu_infer src/SuperPoint.cc:639, sp_extract_stereo :904, fe_lg_stereo_match src/StereoFrontEnd.cc:32), the part
+// after the colon is this library's finer split of that scope.
 struct StageTimer {
   std::vector<std::pair<const char*, hipEvent_t>> marks;
   std::vector<std::pair<std::string, float>> last;
+  ~StageTimer() { clear(); }
   void begin(hipStream_t s) { if (!g_profiling) return; clear(); mark("start", s); }
+  // a matcher entered on its own (no extractor call in front of it on this thread) opens its own sequence
+  void begin_if_idle(hipStream_t s) { if (g_profiling && marks.empty()) mark("start", s); }
   void mark(const char* label, hipStream_t s) {
     if (!g_profiling) return;
+    if (marks.size() >= 64) clear();  // nobody collected: do not accumulate events without bound
     hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s); marks.push_back({label, e});
   }
@@ -288,7 +315,7 @@ struct StageTimer {
     clear();
   }
 };
-static StageTimer g_timer;
+static thread_local StageTimer g_timer;
 
 }  // namespace sship
 
@@ -312,6 +339,7 @@ extern "C" int sship_get_stage_timings(const char** labels, float* ms, int max_s
   return n;
 }
 extern "C" int sship_init(int device) {
+  std::lock_guard<std::mutex> init_guard(g_init_mu);
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(SSHIP_ERR_NO_DEVICE, "no HIP device visible: libsuperslam_hip has no CPU path");
@@ -329,8 +357,8 @@ extern "C" int sship_init(int device) {
   SSHIP_HIP_CHECK(hipGetDeviceProperties(&prop, cur));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(SSHIP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-  g_inited = true;
-  g_device = cur;
+  g_device.store(cur, std::memory_order_release);
+  g_inited.store(true, std::memory_order_release);
   log_msg(2, "sship: device %d %s, %d CUs", cur, prop.gcnArchName, prop.multiProcessorCount);
   return SSHIP_OK;
 }
@@ -343,12 +371,18 @@ extern "C" int sship_device_synchronize(void) {
 // ====================================================================================================
 // descriptor pool  (include/DescriptorPool.h:13-91, src/DescriptorPool.cc:10-38)
 // ====================================================================================================
+// The bookkeeping (free-list + mutex) is reference counted separately from the device slots, like the reference's
+// shared_ptr<FreeList> (DescriptorPool.h:71-75): a DeviceDescriptors handle may outlive the extractor that owns the pool.
+// sship_pool_destroy frees the DEVICE memory (DescriptorPool.cc:27-32 - a surviving handle's data pointer dangles exactly
+// as in the reference) and drops the owner's reference; the struct itself dies with the last handle reference, so a late
+// sship_pool_release never touches freed host memory.
 struct sship_pool {
   int max_keypoints = 0, dim = 0;
   size_t slot_bytes = 0;
-  std::vector<void*> slots;
+  std::vector<void*> slots;     // nullptr once destroyed
   std::vector<int> free_slots;  // LIFO (FreeList)
-  std::mutex mu;                // handles may be released from another thread (async keyframe copies)
+  mutable std::mutex mu;        // handles may be released from another thread (async keyframe copies)
+  std::atomic<int> refs{1};     // owner + one per live handle (sship_pool_retain)
 };
 extern "C" int sship_pool_create(int num_slots, int max_keypoints, int dim, sship_pool** out) {
   bind_thread();
@@ -367,11 +401,20 @@ extern "C" int sship_pool_create(int num_slots, int max_keypoints, int dim, sshi
   *out = p;
   return SSHIP_OK;
 }
+extern "C" void sship_pool_retain(sship_pool* pool) {
+  if (pool) pool->refs.fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" void sship_pool_release_ref(sship_pool* pool) {
+  if (pool && pool->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete pool;
+}
 extern "C" void sship_pool_destroy(sship_pool* pool) {
   bind_thread();
   if (!pool) return;
-  for (void* s : pool->slots) if (s) (void)hipFree(s);
-  delete pool;
+  {
+    std::lock_guard<std::mutex> g(pool->mu);
+    for (void*& s : pool->slots) { if (s) (void)hipFree(s); s = nullptr; }
+  }
+  sship_pool_release_ref(pool);
 }
 extern "C" int sship_pool_acquire(sship_pool* pool) {
   bind_thread();
@@ -391,11 +434,13 @@ extern "C" void sship_pool_release(sship_pool* pool, int slot) {
 extern "C" int sship_pool_in_use(const sship_pool* pool) {
   bind_thread();
   if (!pool) return 0;
+  std::lock_guard<std::mutex> g(pool->mu);
   return (int)pool->slots.size() - (int)pool->free_slots.size();
 }
 extern "C" void* sship_pool_slot_ptr(const sship_pool* pool, int slot) {
   bind_thread();
   if (!pool || slot < 0 || slot >= (int)pool->slots.size()) return nullptr;
+  std::lock_guard<std::mutex> g(pool->mu);
   return pool->slots[slot];
 }
 
@@ -569,14 +614,14 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
   SSHIP_HIP_CHECK(conv3(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, s));
   SSHIP_HIP_CHECK(conv3(sp->c4a, sp->a3b.as<_Float16>(), sp->a4a.as<_Float16>(), B, Hc, Wc, false, s));
   SSHIP_HIP_CHECK(conv3(sp->c4b, sp->a4a.as<_Float16>(), sp->a4b.as<_Float16>(), B, Hc, Wc, false, s));
-  g_timer.mark("sp_encoder", s);
+  g_timer.mark("sp_gpu_infer:encoder", s);
   SSHIP_HIP_CHECK(conv3(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, s));
   SSHIP_HIP_CHECK(sp_conv1x1_f32(sp->cPb, sp->aPa.as<_Float16>(), sp->logits.as<float>(), kLogitStride, B, Hc, Wc, s));
   // the dense descriptor branch (convDa, convDb) is only materialised for the dense API; extraction evaluates both
   // layers at the selected keypoints (k_desc_head_sparse).  SUPERSLAM_HIP_DESC=dense: dense convDa + gather (A/B runs).
   if (dense_desc || desc_dense_mode()) SSHIP_HIP_CHECK(conv3(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
   if (dense_desc) SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
-  g_timer.mark("sp_heads", s);
+  g_timer.mark("sp_gpu_infer:heads", s);
   return SSHIP_OK;
 }
 
@@ -600,7 +645,7 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
   t.n_out = n_out; t.n_cand_out = nullptr;
   launch_topk(t, B, s);
   SSHIP_HIP_CHECK(hipGetLastError());
-  g_timer.mark("sp_select", s);
+  g_timer.mark("sp_extract_stereo:select", s);
   return SSHIP_OK;
 }
 
@@ -617,7 +662,8 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
   if (int rc = require_device()) return rc;
   StateDict sd; std::string err;
   if (!load_safetensors(cfg->weights_path, sd, err)) return fail(SSHIP_ERR_IO, err);
-  std::unique_ptr<sship_sp> sp(new sship_sp());
+  // every early return below releases what has been uploaded so far (weights, fragments, stream, pool)
+  std::unique_ptr<sship_sp, void (*)(sship_sp*)> sp(new sship_sp(), sship_sp_destroy);
   sp->cfg = *cfg;
   if (sp->cfg.pool_slots <= 0) sp->cfg.pool_slots = 8;
   if (sp->cfg.max_batch <= 0) sp->cfg.max_batch = 2;
@@ -695,7 +741,10 @@ extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, 
                                              float* kp_out, int* n_out, void* stream) {
   bind_thread();
   if (!sp || !imgs || !desc_out || !kp_out || !n_out || batch <= 0) return fail(SSHIP_ERR_INVALID, "sp_extract_batch_device: bad arguments");
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
+  // stream == NULL is the legacy default stream itself (torch's default stream): back-to-back extractor / matcher calls
+  // made with NULL are then ordered with each other and with the caller's own NULL-stream work.  (They used to fall back
+  // to each handle's private stream, which are ordered with the NULL stream but not with one another.)
+  hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = sp_ensure(sp, batch, h, w)) return rc;
   g_timer.begin(s);
   if (int rc = sp_network(sp, imgs, batch, h, w, s, false)) return rc;
@@ -704,7 +753,7 @@ extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, 
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
   SSHIP_HIP_CHECK(desc_head(sp, 0, Hc, Wc, sp->cell_h.as<int>(), sp->cell_w.as<int>(), n_out, batch, static_cast<_Float16*>(desc_out),
                             (size_t)sp->cfg.max_keypoints * 256, s));
-  g_timer.mark("sp_gather", s);
+  g_timer.mark("sp_extract_stereo:gather", s);
   return SSHIP_OK;
 }
 
@@ -712,7 +761,7 @@ extern "C" int sship_sp_dense(sship_sp* sp, const uint8_t* imgs, int batch, int 
                               float* logits, void* stream) {
   bind_thread();
   if (!sp || !imgs || batch <= 0) return fail(SSHIP_ERR_INVALID, "sp_dense: bad arguments");
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = legacy default stream (see sship_sp_extract_batch_device)
   if (int rc = sp_ensure(sp, batch, h, w)) return rc;
   if (int rc = sp_network(sp, imgs, batch, h, w, s, desc_grid != nullptr)) return rc;
   int H2, W2, H4, W4, Hc, Wc;
@@ -740,7 +789,7 @@ extern "C" int sship_mfma_probe(int random_operands, float* tflops) {
 extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms,
                                     double* macs) {
   bind_thread();
-  if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 11) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");
+  if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 14) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");
   if (batch > sp->wsB || h != sp->wsH || w != sp->wsW) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: run the network at this shape first");
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
@@ -762,14 +811,43 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
       case 8: return conv3(sp->cPa, a4b, aPa, batch, Hc, Wc, false, s);
       case 9: return sp_conv1x1_f32(sp->cPb, aPa, sp->logits.as<float>(), kLogitStride, batch, Hc, Wc, s);
       case 10: return conv3(sp->cDa, a4b, aDa, batch, Hc, Wc, false, s);
-      default: return sp_conv1x1_f16(sp->cDb, aDa, sp->draw.as<_Float16>(), batch, Hc, Wc, s);
+      case 11: return sp_conv1x1_f16(sp->cDb, aDa, sp->draw.as<_Float16>(), batch, Hc, Wc, s);
+      case 12: {  // softmax + depth-to-space + NMS + threshold + candidate compaction (k_nms_tile) on the last logits
+        if (hipError_t e = hipMemsetAsync(sp->cand_count.p, 0, (size_t)batch * 4, s)) return e;
+        NmsArgs a{};
+        a.logits = sp->logits.as<float>(); a.ls = kLogitStride; a.B = batch; a.H = Hc * 8; a.W = Wc * 8;
+        a.radius = sp->cfg.nms_radius; a.thr_f = sp->thr_f; a.border = sp->cfg.remove_borders;
+        a.cand = sp->cand.as<unsigned long long>(); a.cand_count = sp->cand_count.as<int>(); a.cap = sp->cap;
+        launch_nms_tile(0, a, s);
+        return hipGetLastError();
+      }
+      case 13: {  // top-k over the candidates left by the last selection (k_topk)
+        TopkArgs t{};
+        t.cand = sp->cand.as<unsigned long long>(); t.cand_count = sp->cand_count.as<int>(); t.cap = sp->cap;
+        t.max_kp = sp->cfg.max_keypoints; t.score_w = Wc * 8;
+        t.scale_x = static_cast<float>(w) / (Wc * 8); t.scale_y = static_cast<float>(h) / (Hc * 8);
+        t.desc_h = Hc; t.desc_w = Wc; t.kp_xys = sp->kp.as<float>(); t.cell_h = sp->cell_h.as<int>(); t.cell_w = sp->cell_w.as<int>();
+        t.n_out = sp->n_dev.as<int>(); t.n_cand_out = nullptr;
+        launch_topk(t, batch, s);
+        return hipGetLastError();
+      }
+      default:  // 14: descriptor head at the selected keypoints (k_desc_head_sparse) into the staging rows
+        if (hipError_t e = sp->desc_stage.ensure((size_t)batch * sp->cfg.max_keypoints * 512)) return e;
+        return desc_head(sp, 0, Hc, Wc, sp->cell_h.as<int>(), sp->cell_w.as<int>(), sp->n_dev.as<int>(), batch, sp->desc_stage.as<_Float16>(),
+                         (size_t)sp->cfg.max_keypoints * 256, s);
     }
   };
+  if (layer >= 13) {  // these read the selection's outputs: produce them once on this handle's own buffers
+    const int keep = layer;
+    layer = 12; SSHIP_HIP_CHECK(run());
+    layer = 13; SSHIP_HIP_CHECK(run());
+    layer = keep;
+  }
   const double px[12] = {(double)h * w, (double)h * w, (double)H2 * W2, (double)H2 * W2, (double)H4 * W4, (double)H4 * W4,
                          (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc};
   const double mpp[12] = {9.0 * 64, 576.0 * 64 + 9.0 * 64 /* conv1a fused */, 576.0 * 64, 576.0 * 64, 576.0 * 128, 1152.0 * 128, 1152.0 * 128,
                           1152.0 * 128, 1152.0 * 256, 256.0 * 65, 1152.0 * 256, 256.0 * 256};
-  if (macs) *macs = px[layer] * mpp[layer] * batch;
+  if (macs) *macs = layer < 12 ? px[layer] * mpp[layer] * batch : 0.0;
   SSHIP_HIP_CHECK(run());  // warm
   hipEvent_t e0, e1;
   SSHIP_HIP_CHECK(hipEventCreate(&e0));
@@ -804,23 +882,31 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
     launch_bgr2gray(sp->gray_in.as<uint8_t>(), B * h * w, sp->img.as<uint8_t>(), s);
   }
   g_timer.begin(s);
+  for (int b = 0; b < B; ++b) { outs[b]->n = 0; outs[b]->desc_dev = nullptr; outs[b]->slot = -1; }
   if (int rc = sp_network(sp, gray, B, h, w, s, false)) return rc;
   if (int rc = sp_select(sp, B, h, w, nullptr, sp->kp.as<float>(), sp->n_dev.as<int>(), s)) return rc;
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
   const int mk = sp->cfg.max_keypoints;
   int rc_pool = SSHIP_OK;
+  // a HIP failure after slots were acquired hands them back: the 8-slot pool must not shrink with every error
+  auto give_back = [&](hipError_t e, const char* what) {
+    (void)hipStreamSynchronize(s);
+    for (int b = 0; b < B; ++b)
+      if (outs[b]->slot >= 0) { sship_pool_release(sp->pool, outs[b]->slot); outs[b]->slot = -1; outs[b]->desc_dev = nullptr; outs[b]->n = 0; }
+    return fail(SSHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  };
   for (int b = 0; b < B; ++b) {
-    outs[b]->n = 0; outs[b]->desc_dev = nullptr;
     outs[b]->slot = sship_pool_acquire(sp->pool);  // pool_->make(n), SuperPoint.cc:721
     if (outs[b]->slot < 0) { rc_pool = SSHIP_ERR_POOL_EXHAUSTED; continue; }
-    SSHIP_HIP_CHECK(desc_head(sp, b, Hc, Wc, sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
-                              sp->n_dev.as<int>() + b, 1, static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), 0, s));
+    if (hipError_t e = desc_head(sp, b, Hc, Wc, sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
+                                 sp->n_dev.as<int>() + b, 1, static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), 0, s))
+      return give_back(e, "sp_extract: descriptor head");
   }
-  g_timer.mark("sp_gather", s);
-  SSHIP_HIP_CHECK(hipMemcpyAsync(sp->h_kp.p, sp->kp.p, (size_t)B * mk * 12, hipMemcpyDeviceToHost, s));
-  SSHIP_HIP_CHECK(hipMemcpyAsync(sp->h_n.p, sp->n_dev.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-  SSHIP_HIP_CHECK(hipStreamSynchronize(s));
+  g_timer.mark("sp_extract_stereo:gather", s);
+  if (hipError_t e = hipMemcpyAsync(sp->h_kp.p, sp->kp.p, (size_t)B * mk * 12, hipMemcpyDeviceToHost, s)) return give_back(e, "sp_extract: D2H keypoints");
+  if (hipError_t e = hipMemcpyAsync(sp->h_n.p, sp->n_dev.p, (size_t)B * 4, hipMemcpyDeviceToHost, s)) return give_back(e, "sp_extract: D2H counts");
+  if (hipError_t e = hipStreamSynchronize(s)) return give_back(e, "sp_extract: stream synchronize");
   for (int b = 0; b < B; ++b) {
     const int n = sp->h_n.as<int>()[b];
     outs[b]->n = n;
@@ -1035,6 +1121,10 @@ struct sship_lg {
   hipStream_t stream = nullptr;
   DevBuf x, rope, q, k, vt, ctx, md, logsig, sim, ws;
   DevBuf kp_stage, desc_stage, lens, m0, ms0;
+  DevBuf lens_c;  // per-sequence counts clamped to [0, max_kp] by k_lg_prep: what every later kernel of the call reads
+  DevBuf kpn;     // normalised keypoints [S*NP][2] f32 (src/LightGlue.cc:241-251 on the device; read back by sship_lg_debug_read)
+  int debug_layers = kLgLayers;  // sship_lg_debug_set_layers
+  int last_pairs = 0;
   PinBuf h_kp, h_lens, h_m0, h_ms0, h_desc;
 };
 
@@ -1061,6 +1151,8 @@ extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, in
   SSHIP_HIP_CHECK(lg->kp_stage.ensure(S * max_kp * 3 * 4));
   SSHIP_HIP_CHECK(lg->desc_stage.ensure(S * max_kp * 256 * 2));
   SSHIP_HIP_CHECK(lg->lens.ensure(S * 4));
+  SSHIP_HIP_CHECK(lg->lens_c.ensure(S * 4));
+  SSHIP_HIP_CHECK(lg->kpn.ensure(T * 2 * 4));
   SSHIP_HIP_CHECK(lg->m0.ensure((size_t)max_pairs * max_kp * 4));
   SSHIP_HIP_CHECK(lg->ms0.ensure((size_t)max_pairs * max_kp * 4));
   SSHIP_HIP_CHECK(lg->h_kp.ensure(2 * (size_t)max_kp * 3 * 4));
@@ -1098,6 +1190,46 @@ extern "C" int sship_lg_normalize_keypoints(const sship_lg* lg, const float* kp,
   return SSHIP_OK;
 }
 
+// Test-only introspection (include/sship.h): truncate the matcher after n layers / read its internal state back.
+extern "C" int sship_lg_debug_set_layers(sship_lg* lg, int n_layers) {
+  if (!lg || n_layers < 1 || n_layers > kLgLayers) return fail(SSHIP_ERR_INVALID, "lg_debug_set_layers: n_layers must be in [1, 9]");
+  lg->debug_layers = n_layers;
+  return SSHIP_OK;
+}
+extern "C" int sship_lg_debug_read(sship_lg* lg, int what, int index, int rows, int cols, float* out) {
+  bind_thread();
+  if (!lg || !out || rows <= 0 || index < 0) return fail(SSHIP_ERR_INVALID, "lg_debug_read: bad arguments");
+  const int NP = lg->NP, S = 2 * lg->last_pairs;
+  if (rows > NP) return fail(SSHIP_ERR_INVALID, "lg_debug_read: rows exceeds the padded sequence length");
+  SSHIP_HIP_CHECK(hipDeviceSynchronize());
+  switch (what) {
+    case SSHIP_LG_DEBUG_X: {  // residual stream of sequence `index`: fp16 [NP][256]
+      if (index >= S || cols != 256) return fail(SSHIP_ERR_INVALID, "lg_debug_read(X): index/cols");
+      std::vector<uint16_t> tmp((size_t)rows * 256);
+      SSHIP_HIP_CHECK(hipMemcpy(tmp.data(), lg->x.as<_Float16>() + (size_t)index * NP * 256, tmp.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < tmp.size(); ++i) out[i] = half_bits_to_float(tmp[i]);
+      return SSHIP_OK;
+    }
+    case SSHIP_LG_DEBUG_SIM: {  // assignment similarity of pair `index`: f32 [NP][NP]
+      if (index >= S / 2 || cols <= 0 || cols > NP) return fail(SSHIP_ERR_INVALID, "lg_debug_read(SIM): index/cols");
+      SSHIP_HIP_CHECK(hipMemcpy2D(out, (size_t)cols * 4, lg->sim.as<float>() + (size_t)index * NP * NP, (size_t)NP * 4, (size_t)cols * 4, rows,
+                                  hipMemcpyDeviceToHost));
+      return SSHIP_OK;
+    }
+    case SSHIP_LG_DEBUG_KPTS: {  // normalised keypoints of sequence `index`: f32 [NP][2]
+      if (index >= S || cols != 2) return fail(SSHIP_ERR_INVALID, "lg_debug_read(KPTS): index/cols");
+      SSHIP_HIP_CHECK(hipMemcpy(out, lg->kpn.as<float>() + (size_t)index * NP * 2, (size_t)rows * 8, hipMemcpyDeviceToHost));
+      return SSHIP_OK;
+    }
+    case SSHIP_LG_DEBUG_ROPE: {  // rotary table of sequence `index`: f32 [NP][32] (cos, sin) pairs
+      if (index >= S || cols != 64) return fail(SSHIP_ERR_INVALID, "lg_debug_read(ROPE): index/cols");
+      SSHIP_HIP_CHECK(hipMemcpy(out, lg->rope.as<float>() + (size_t)index * NP * 64, (size_t)rows * 256, hipMemcpyDeviceToHost));
+      return SSHIP_OK;
+    }
+    default: return fail(SSHIP_ERR_INVALID, "lg_debug_read: unknown selector");
+  }
+}
+
 // The matcher proper: `pairs` problems, everything on the device.  9 x (SelfBlock x2 images, CrossBlock), then
 // log_assignment[8] + filter_matches.
 static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_stride, const int* lens,
@@ -1108,14 +1240,19 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   _Float16 *x = lg->x.as<_Float16>(), *q = lg->q.as<_Float16>(), *k = lg->k.as<_Float16>(), *vt = lg->vt.as<_Float16>();
   _Float16* ctx = lg->ctx.as<_Float16>();
   float* rope = lg->rope.as<float>();
-  launch_lg_prep(kp, kp_stride, kp_seq_stride, lens, desc, desc_seq_stride, w->wr, (float)lg->image_w,
-                 (float)lg->image_h, d, x, rope, s);
+  // prep also publishes the counts clamped to [0, max_kp] (a caller-supplied count above max_kp would otherwise read past
+  // the descriptor / keypoint stride of its sequence): every kernel below reads the clamped copy.
+  launch_lg_prep(kp, kp_stride, kp_seq_stride, lens, lg->max_kp, lg->lens_c.as<int>(), desc, desc_seq_stride, w->wr,
+                 (float)lg->image_w, (float)lg->image_h, d, x, rope, lg->kpn.as<float>(), s);
+  lens = lg->lens_c.as<int>();
+  lg->last_pairs = pairs;
   // 3 launches per block: [projection fused into the previous FFN's tail] -> attention -> FFN(+ next projection).
   static const bool igemm_qkv0 = getenv("SUPERSLAM_HIP_LG_QKV0") && std::string(getenv("SUPERSLAM_HIP_LG_QKV0")) == "igemm";  // A/B
   if (igemm_qkv0) SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
   else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
-  g_timer.mark("lg_posenc_qkv0", s);
-  for (int i = 0; i < kLgLayers; ++i) {
+  g_timer.mark("fe_lg_stereo_match:posenc_qkv0", s);
+  const int n_layers = lg->debug_layers;  // kLgLayers except under sship_lg_debug_set_layers (test-only)
+  for (int i = 0; i < n_layers; ++i) {
     // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
     launch_lg_attention(q, k, vt, lens, d, false, ctx, s);
     launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], ctx, x, d, &w->cqkv_t[i], true, /*rope_segs=*/0,
@@ -1131,12 +1268,17 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
                     lg->md.as<_Float16>(), w->match_w, w->match_b, lg->logsig.as<float>(), s);
   }
   SSHIP_HIP_CHECK(hipGetLastError());
-  g_timer.mark("lg_layers_x9", s);
+  g_timer.mark("fe_lg_stereo_match:layers_x9", s);
+  if (n_layers < kLgLayers) {  // truncated debug run: x after layer n_layers is the product; no assignment
+    SSHIP_HIP_CHECK(hipMemsetAsync(m0, 0xff, (size_t)pairs * lg->max_kp * 4, s));
+    SSHIP_HIP_CHECK(hipMemsetAsync(ms0, 0, (size_t)pairs * lg->max_kp * 4, s));
+    return SSHIP_OK;
+  }
   launch_lg_sim(lg->md.as<_Float16>(), lens, d, lg->sim.as<float>(), s);
   launch_lg_assign(lg->sim.as<float>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->max_kp, m0, ms0,
                    0.1f /* filter_threshold */, s);
   SSHIP_HIP_CHECK(hipGetLastError());
-  g_timer.mark("lg_assign_filter", s);
+  g_timer.mark("fe_lg_stereo_match:assign_filter", s);
   return SSHIP_OK;
 }
 
@@ -1145,15 +1287,69 @@ extern "C" int sship_lg_match_batch_device(sship_lg* lg, const float* kp, const 
   bind_thread();
   if (!lg || !kp || !n || !desc || !m0 || !ms0) return fail(SSHIP_ERR_INVALID, "lg_match_batch_device: null argument");
   if (pairs <= 0 || pairs > lg->max_pairs) return fail(SSHIP_ERR_INVALID, "lg_match_batch_device: pairs exceeds max_pairs");
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lg->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = legacy default stream: ordered after an extractor call made with NULL
+  g_timer.begin_if_idle(s);
   return lg_forward(lg, kp, 3, lg->max_kp * 3, n, static_cast<const _Float16*>(desc), (size_t)lg->max_kp * 256, pairs,
                     m0, ms0, s);
+}
+
+// Measurement hook (include/sship.h): one stage of the matcher re-launched `iters` times over the state of the last call.
+extern "C" int sship_lg_bench_stage(sship_lg* lg, int stage, int iters, float* avg_ms) {
+  bind_thread();
+  if (!lg || !avg_ms || iters <= 0 || stage < 0 || stage > 7) return fail(SSHIP_ERR_INVALID, "lg_bench_stage: bad arguments");
+  if (lg->last_pairs <= 0) return fail(SSHIP_ERR_INVALID, "lg_bench_stage: run a match on this handle first");
+  const sship_lg_weights* w = lg->w;
+  const int pairs = lg->last_pairs;
+  LgDims d{2 * pairs, lg->NP};
+  hipStream_t s = lg->stream;
+  _Float16 *x = lg->x.as<_Float16>(), *q = lg->q.as<_Float16>(), *k = lg->k.as<_Float16>(), *vt = lg->vt.as<_Float16>();
+  _Float16* ctx = lg->ctx.as<_Float16>();
+  float* rope = lg->rope.as<float>();
+  const int* lens = lg->lens_c.as<int>();
+  auto run = [&]() -> hipError_t {
+    switch (stage) {
+      case 0: return launch_lg_proj_heads(w->qkv_t[0], x, d, 2, 2, rope, q, k, vt, s);
+      case 1: launch_lg_attention(q, k, vt, lens, d, false, ctx, s); return hipGetLastError();
+      case 2: launch_lg_attention(q, q, vt, lens, d, true, ctx, s); return hipGetLastError();
+      case 3: launch_lg_ffn(w->ffn0_s[0], w->ffn3_s[0], w->ln_g_s[0], w->ln_b_s[0], ctx, x, d, &w->cqkv_t[0], true, 0, 1, rope, q, k, vt,
+                            nullptr, nullptr, 0.f, nullptr, s); return hipGetLastError();
+      case 4: launch_lg_ffn(w->ffn0_c[0], w->ffn3_c[0], w->ln_g_c[0], w->ln_b_c[0], ctx, x, d, &w->qkv_t[1], true, 2, 2, rope, q, k, vt,
+                            nullptr, nullptr, 0.f, nullptr, s); return hipGetLastError();
+      case 5: launch_lg_ffn(w->ffn0_c[8], w->ffn3_c[8], w->ln_g_c[8], w->ln_b_c[8], ctx, x, d, &w->final_t, false, 0, 0, rope, q, k, vt,
+                            lg->md.as<_Float16>(), w->match_w, w->match_b, lg->logsig.as<float>(), s); return hipGetLastError();
+      case 6: launch_lg_sim(lg->md.as<_Float16>(), lens, d, lg->sim.as<float>(), s); return hipGetLastError();
+      default: launch_lg_assign(lg->sim.as<float>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->max_kp, lg->m0.as<int32_t>(),
+                                lg->ms0.as<float>(), 0.1f, s); return hipGetLastError();
+    }
+  };
+  // stages 3 / 4 update the residual stream in place: keep a copy and put it back (the values do not affect the timing, but
+  // the handle's state should be what the last match left)
+  DevBuf keep;
+  const size_t xbytes = (size_t)d.S * d.NP * 512;
+  SSHIP_HIP_CHECK(keep.ensure(xbytes));
+  SSHIP_HIP_CHECK(hipMemcpyAsync(keep.p, x, xbytes, hipMemcpyDeviceToDevice, s));
+  SSHIP_HIP_CHECK(run());  // warm
+  hipEvent_t e0, e1;
+  SSHIP_HIP_CHECK(hipEventCreate(&e0));
+  SSHIP_HIP_CHECK(hipEventCreate(&e1));
+  SSHIP_HIP_CHECK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) SSHIP_HIP_CHECK(run());
+  SSHIP_HIP_CHECK(hipEventRecord(e1, s));
+  SSHIP_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SSHIP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  SSHIP_HIP_CHECK(hipMemcpyAsync(x, keep.p, xbytes, hipMemcpyDeviceToDevice, s));
+  SSHIP_HIP_CHECK(hipStreamSynchronize(s));
+  *avg_ms = ms / iters;
+  return SSHIP_OK;
 }
 
 static int lg_match_common(sship_lg* lg, const float* kp0, int st0, int n0, const float* kp1, int st1, int n1,
                            int32_t* matches0, float* mscores0) {
   // kpts -> pinned [2, max_kp, 3] (x, y, 0) -> device; descriptors already staged in desc_stage.
   hipStream_t s = lg->stream;
+  g_timer.begin_if_idle(s);
   float* hk = lg->h_kp.as<float>();
   const int mk = lg->max_kp;
   for (int i = 0; i < n0; ++i) { hk[3 * i] = kp0[(size_t)i * st0]; hk[3 * i + 1] = kp0[(size_t)i * st0 + 1]; hk[3 * i + 2] = 0.f; }
@@ -1226,7 +1422,7 @@ extern "C" int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uin
   if (!sp || !lg || !imgs || !desc_out || !kp_out || !n_out || !m0 || !ms0) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: null argument");
   if (pairs <= 0 || pairs > lg->max_pairs) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: pairs exceeds the matcher's max_pairs");
   if (sp->cfg.max_keypoints != lg->max_kp) return fail(SSHIP_ERR_INVALID, "frontend_batch_device: extractor and matcher disagree on max_keypoints");
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : sp->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // one stream for the extractor and the matcher; NULL = legacy default stream
   if (int rc = sship_sp_extract_batch_device(sp, imgs, 2 * pairs, h, w, desc_out, kp_out, n_out, s)) return rc;
   return lg_forward(lg, kp_out, 3, lg->max_kp * 3, n_out, static_cast<const _Float16*>(desc_out), (size_t)lg->max_kp * 256,
                     pairs, m0, ms0, s);

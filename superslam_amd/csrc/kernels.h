@@ -86,9 +86,9 @@ struct LgDims {
   int S;    // sequences (2 * pairs)
   int NP;   // padded tokens per sequence (multiple of 128)
 };
-void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int* lens, const _Float16* desc,
-                    size_t desc_seq_stride, const float* wr, float img_w, float img_h, LgDims d, _Float16* x,
-                    float* rope, hipStream_t s);
+void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int* lens, int max_kp, int* lens_clamped,
+                    const _Float16* desc, size_t desc_seq_stride, const float* wr, float img_w, float img_h, LgDims d,
+                    _Float16* x, float* rope, float* kpn, hipStream_t s);
 hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope_segs, int t_seg,
                            const float* rope, _Float16* q, _Float16* k, _Float16* vt, hipStream_t s);
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,

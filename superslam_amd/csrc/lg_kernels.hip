@@ -15,40 +15,47 @@ namespace sship {
 // reference: keypoint normalisation src/LightGlue.cc:241-251; LearnableFourierPositionalEncoding(2,64,64).
 // rope[token][i] = (cos, sin)(Wr[i,0]*kx + Wr[i,1]*ky), i < 32 (shared by the 4 heads).
 // ---------------------------------------------------------------------------------------------------
+// Also publishes lens_clamped[s] = clamp(lens[s], 0, max_kp) for the rest of the call and the normalised keypoints (kpn,
+// zeros for padding rows) for the parity suite's bit-exact check of the normalisation.
 __global__ __launch_bounds__(256) void k_lg_prep(const float* __restrict__ kp, int kp_stride, int kp_seq_stride,
-                                                 const int* __restrict__ lens, const _Float16* __restrict__ desc,
+                                                 const int* __restrict__ lens, int max_kp, int* __restrict__ lens_clamped,
+                                                 const _Float16* __restrict__ desc,
                                                  size_t desc_seq_stride, const float* __restrict__ wr, float img_w,
                                                  float img_h, int S, int NP, _Float16* __restrict__ x,
-                                                 float* __restrict__ rope) {
+                                                 float* __restrict__ rope, float* __restrict__ kpn) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < S) lens_clamped[threadIdx.x] = min(max(lens[threadIdx.x], 0), max_kp);
+  if (blockIdx.x == 0)
+    for (int i = 256 + threadIdx.x; i < S; i += 256) lens_clamped[i] = min(max(lens[i], 0), max_kp);
   const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (token >= S * NP) return;
   const int s = token / NP, n = token % NP;
-  const bool valid = n < min(max(lens[s], 0), NP);
+  const bool valid = n < min(max(lens[s], 0), max_kp);
   h4_t v = to_h4(0.f, 0.f, 0.f, 0.f);
   if (valid) v = *reinterpret_cast<const h4_t*>(desc + (size_t)s * desc_seq_stride + (size_t)n * 256 + lane * 4);
   *reinterpret_cast<h4_t*>(x + (size_t)token * 256 + lane * 4) = v;
   if (lane < 32) {
-    float c = 1.f, sn = 0.f;
+    float c = 1.f, sn = 0.f, kx = 0.f, ky = 0.f;
     if (valid) {
       const float* k = kp + (size_t)s * kp_seq_stride + (size_t)n * kp_stride;
       const float scale = fmaxf(img_w, img_h) / 2.0f;   // std::max(w, h) / 2.0f
-      const float kx = (k[0] - img_w / 2.0f) / scale;   // (pt.x - cx) / scale
-      const float ky = (k[1] - img_h / 2.0f) / scale;
+      kx = (k[0] - img_w / 2.0f) / scale;               // (pt.x - cx) / scale : IEEE division, as the host code
+      ky = (k[1] - img_h / 2.0f) / scale;
       const float pr = wr[lane * 2 + 0] * kx + wr[lane * 2 + 1] * ky;
       c = cosf(pr);
       sn = sinf(pr);
     }
+    if (lane == 0) { kpn[(size_t)token * 2 + 0] = kx; kpn[(size_t)token * 2 + 1] = ky; }
     rope[(size_t)token * 64 + lane * 2 + 0] = c;
     rope[(size_t)token * 64 + lane * 2 + 1] = sn;
   }
 }
-void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int* lens, const _Float16* desc,
-                    size_t desc_seq_stride, const float* wr, float img_w, float img_h, LgDims d, _Float16* x,
-                    float* rope, hipStream_t s) {
+void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int* lens, int max_kp, int* lens_clamped,
+                    const _Float16* desc, size_t desc_seq_stride, const float* wr, float img_w, float img_h, LgDims d,
+                    _Float16* x, float* rope, float* kpn, hipStream_t s) {
   const int tokens = d.S * d.NP;
-  hipLaunchKernelGGL(k_lg_prep, dim3((tokens + 3) / 4), dim3(256), 0, s, kp, kp_stride, kp_seq_stride, lens, desc,
-                     desc_seq_stride, wr, img_w, img_h, d.S, d.NP, x, rope);
+  hipLaunchKernelGGL(k_lg_prep, dim3((tokens + 3) / 4), dim3(256), 0, s, kp, kp_stride, kp_seq_stride, lens, max_kp,
+                     lens_clamped, desc, desc_seq_stride, wr, img_w, img_h, d.S, d.NP, x, rope, kpn);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -931,7 +938,7 @@ __global__ __launch_bounds__(256) void k_assign_row_arg(const float* __restrict_
   const float* ls1 = logsig + (size_t)(2 * pair + 1) * NP;
   const float li = w[i], ls0 = logsig[(size_t)(2 * pair) * NP + i];
   float best = -INFINITY;
-  int bj = 0x7fffffff;
+  int bj = 0;  // a row of NaN / -inf scores keeps index 0, like torch.max on a degenerate row (never an out-of-range index)
   for (int j = lane; j < n1; j += 64) {
     const float v = ((row[j] - li) + (row[j] - w[NP + j])) + (ls0 + ls1[j]);
     if (v > best) { best = v; bj = j; }
@@ -953,7 +960,7 @@ __global__ __launch_bounds__(64 * kColRG) void k_assign_col_arg(const float* __r
   const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   float* w = ws + (size_t)pair * 5 * NP;
   float best = -INFINITY;
-  int bi = 0x7fffffff;
+  int bi = 0;
   if (j < n1) {
     const float* col = sim + (size_t)pair * NP * NP + j;
     const float* ls0 = logsig + (size_t)(2 * pair) * NP;
@@ -983,7 +990,7 @@ __global__ void k_assign_final(const int* __restrict__ lens, int NP, const float
   float ms = 0.f;
   if (i < n0 && n1 > 0) {
     const int j = reinterpret_cast<const int*>(w)[3 * NP + i];
-    const bool mutual = reinterpret_cast<const int*>(w)[4 * NP + j] == i;
+    const bool mutual = (unsigned)j < (unsigned)n1 && reinterpret_cast<const int*>(w)[4 * NP + j] == i;
     ms = mutual ? expf(w[2 * NP + i]) : 0.f;
     mj = (mutual && ms > thr) ? j : -1;
   }

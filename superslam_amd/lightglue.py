@@ -128,6 +128,17 @@ class LightGlue:
         _lib.check(_lib.lib().sship_desc_to_host(d.data, d.count, d.dim, out.ctypes.data))
         return out
 
+    # ---- test-only introspection (include/sship.h sship_lg_debug_*): the parity suite compares internals with the oracle
+    DEBUG_X, DEBUG_SIM, DEBUG_KPTS, DEBUG_ROPE = 0, 1, 2, 3
+
+    def debug_set_layers(self, n_layers: int) -> None:
+        _lib.check(_lib.lib().sship_lg_debug_set_layers(self._h, int(n_layers)))
+
+    def debug_read(self, what: int, index: int, rows: int, cols: int) -> np.ndarray:
+        out = np.zeros((rows, cols), np.float32)
+        _lib.check(_lib.lib().sship_lg_debug_read(self._h, what, index, rows, cols, out.ctypes.data))
+        return out
+
     def match_batch_device(self, kp, n, desc, matches0=None, mscores0=None, stream=None):
         """kp f32 [2P,K,3], n i32 [2P], desc f16 [2P,K,256] (torch CUDA) -> matches0 i32 [P,K], mscores0 f32 [P,K]."""
         import torch

@@ -7,15 +7,23 @@ from . import _lib
 
 
 class _SlotRef:
-    """shared_ptr<void> slot_ref: returns the slot to the pool when the last copy dies."""
+    """shared_ptr<void> slot_ref: returns the slot to the pool when the last copy dies.
+
+    Holds its own reference on the pool's bookkeeping (sship_pool_retain), so it may run after the extractor that
+    owns the pool was closed - in any order at interpreter exit - like the reference's deleter, which captures the
+    shared FreeList and not the pool (include/DescriptorPool.h:71-75)."""
 
     def __init__(self, pool, slot):
         self.pool, self.slot = pool, slot
+        _lib.lib().sship_pool_retain(pool)
 
     def __del__(self):
         try:
             if self.pool is not None and self.slot >= 0:
-                _lib.lib().sship_pool_release(self.pool, self.slot)
+                L = _lib.lib()
+                L.sship_pool_release(self.pool, self.slot)
+                L.sship_pool_release_ref(self.pool)
+                self.pool = None
         except Exception:
             pass
 
@@ -40,6 +48,18 @@ class DescriptorPool:
         self._h = C.c_void_p()
         _lib.check(_lib.lib().sship_pool_create(num_slots, max_keypoints, dim, C.byref(self._h)))
         self._dim, self._max_kp = dim, max_keypoints
+
+    def close(self) -> None:
+        """Free the device slots (DescriptorPool.cc:27-32); handles made from this pool stay safe to drop."""
+        if self._h:
+            _lib.lib().sship_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def make(self, count: int) -> DeviceDescriptors:
         slot = _lib.lib().sship_pool_acquire(self._h)

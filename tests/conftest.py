@@ -40,3 +40,22 @@ def weights_dir(tmp_path_factory):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def parity_report():
+    """Measured parity numbers of the GPU suite (IoU, flips, ulps, agreement, |d|), written at session end to
+    gpurun_out/parity_report.json (merged back from the GPU box; the copy kept for the record is profiles/parity_report.json)."""
+    import json
+
+    rep = {}
+    yield rep
+    if not rep:
+        return
+    for d in (os.path.join(ROOT, "gpurun_out"),):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "parity_report.json"), "w") as f:
+                json.dump(rep, f, indent=1, sort_keys=True)
+        except OSError:
+            pass

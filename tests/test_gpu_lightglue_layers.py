@@ -1,0 +1,269 @@
+"""GPU (-m gpu): LightGlue internals through the test-only debug ABI (sship_lg_debug_*) against the fp64 oracle.
+
+The end-to-end bars (matches0 agreement >= 0.99, |d mscores0| <= 2e-2) are only meaningful because every broken
+variant of the algorithm violates them on these weights (tests/test_lightglue_known_answers.py, mutation table).  This
+file adds the layer-by-layer view: normalised keypoints (bit-exact), rotary table, the residual stream after layers
+1 / 5 / 9 and the assignment similarity, at N in {7x5, 64, 97x130, 600, 1024} and ragged lengths; plus full-size
+properties (translation invariance, permutation equivariance, padding / batch-slot invariance).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hostpath as H  # noqa: E402
+from oracle import lightglue_ref as LR  # noqa: E402
+
+X_REL_BAR = 4e-3      # ||x_gpu - x_ref|| / ||x_ref|| per sequence and layer (fp16 stream: ~1e-3 expected)
+X_ABS_BAR = 6e-3      # max |x_gpu - x_ref| (x elements are O(0.1 .. 1))
+SIM_REL_BAR = 4e-3    # max |sim_gpu - sim_ref| / max |sim_ref|
+W, HH = 1376, 376
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from superslam_amd import _lib
+
+    _lib.init()
+    assert torch.cuda.is_available()
+    return _lib.lib()
+
+
+def _make_lg(weights_dir, max_kp, max_pairs=1):
+    from superslam_amd import LightGlue
+
+    m = LightGlue(weights_dir["lg_path"], W, HH, max_keypoints=max_kp, max_pairs=max_pairs)
+    assert m.initialize(), m.last_error
+    return m
+
+
+@pytest.fixture(scope="module")
+def lg(hip, weights_dir):
+    m = _make_lg(weights_dir, 600, 2)
+    yield m
+    m.close()
+
+
+def _px(k):
+    """normalised [N,2] -> pixel coordinates whose normalisation returns k up to fp32 rounding."""
+    s = max(W, HH) / 2.0
+    return (np.asarray(k, np.float64) * s + np.array([W / 2.0, HH / 2.0])).astype(np.float32)
+
+
+def _random_sets(n0, n1, seed):
+    g = torch.Generator().manual_seed(seed)
+    k0 = (torch.rand((n0, 2), generator=g) * 2 - 1) * torch.tensor([1.0, 0.27])
+    d0 = torch.nn.functional.normalize(torch.randn((n0, 256), generator=g), dim=-1)
+    perm = torch.randperm(max(n0, n1), generator=g)[:n1] % n0
+    k1 = k0[perm] + 0.01 * torch.randn((n1, 2), generator=g)
+    d1 = torch.nn.functional.normalize(d0[perm] + 0.15 * torch.randn((n1, 256), generator=g), dim=-1)
+    return k0.numpy(), d0.half().float().numpy(), k1.numpy(), d1.half().float().numpy()
+
+
+def _oracle(weights_dir, px0, d0, px1, d1, dtype=torch.float64):
+    nk0, nk1 = H.normalize_kpts(px0, W, HH), H.normalize_kpts(px1, W, HH)
+    with torch.no_grad():
+        m, s, it = LR.match(weights_dir["lg"], torch.from_numpy(nk0)[None], torch.from_numpy(d0)[None],
+                            torch.from_numpy(nk1)[None], torch.from_numpy(d1)[None], dtype=dtype, return_internals=True)
+    return m[0].numpy(), s[0].numpy(), it
+
+
+# ------------------------------------------------------------------------------------------------------
+# a12: keypoint normalisation - host helper and device kernel, bit-exact against the committed table
+# ------------------------------------------------------------------------------------------------------
+def test_normalize_keypoints_host_and_device_bit_exact(hip, weights_dir, golden_dir):
+    from superslam_amd import LightGlue
+
+    with open(os.path.join(golden_dir, "meta.json")) as f:
+        t = json.load(f)["normalize_kpts"]
+    m = LightGlue(weights_dir["lg_path"], t["image_w"], t["image_h"], max_keypoints=64)
+    assert m.initialize(), m.last_error
+    kp = np.array(t["kp"], np.float32)
+    exp = np.array(t["expected"], np.float32)
+    np.testing.assert_array_equal(m.normalize_keypoints(kp), exp)                      # sship_lg_normalize_keypoints
+    np.testing.assert_array_equal(m.normalize_keypoints(np.concatenate([kp, kp[:, :1]], 1)), exp)   # stride 3 (x, y, score)
+    rng = np.random.default_rng(3)
+    more = np.stack([rng.uniform(0, t["image_w"], 59), rng.uniform(0, t["image_h"], 59)], 1).astype(np.float32)
+    allk = np.concatenate([kp, more])
+    d = rng.standard_normal((len(allk), 256)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    m.match(allk, d, allk[::-1].copy(), d[::-1].copy())
+    ref = H.normalize_kpts(allk, t["image_w"], t["image_h"])
+    got0 = m.debug_read(m.DEBUG_KPTS, 0, len(allk), 2)                                  # k_lg_prep on the device
+    got1 = m.debug_read(m.DEBUG_KPTS, 1, len(allk), 2)
+    np.testing.assert_array_equal(got0, ref)
+    np.testing.assert_array_equal(got1, ref[::-1])
+    np.testing.assert_array_equal(got0[: len(kp)], exp)
+    # rotary table = (cos, sin)(Wr k) interleaved per frequency
+    wr = weights_dir["lg"]["posenc.Wr.weight"].double().numpy()
+    ph = ref.astype(np.float64) @ wr.T
+    rope = m.debug_read(m.DEBUG_ROPE, 0, len(allk), 64)
+    np.testing.assert_allclose(rope[:, 0::2], np.cos(ph), atol=3e-5)
+    np.testing.assert_allclose(rope[:, 1::2], np.sin(ph), atol=3e-5)
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------------------
+# a14: residual stream and assignment similarity, layer by layer
+# ------------------------------------------------------------------------------------------------------
+def _check_layers(m, weights_dir, px0, d0, px1, d1, tag, parity_report, layers=(1, 5, 9), it=None, golden=None):
+    n0, n1 = len(px0), len(px1)
+    if it is None:
+        _, _, it = _oracle(weights_dir, px0, d0, px1, d1)
+    worst = 0.0
+    for nl in layers:
+        m.debug_set_layers(nl)
+        m.match(px0, d0, px1, d1)
+        for seq, (n, key) in enumerate(((n0, "x0_layers"), (n1, "x1_layers"))):
+            got = m.debug_read(m.DEBUG_X, seq, n, 256)
+            ref = it[key][nl - 1][0].double().numpy()
+            rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            mx = np.abs(got - ref).max()
+            worst = max(worst, rel)
+            print(f"LG layers {tag}: after layer {nl} seq {seq}: rel {rel:.2e} max|d| {mx:.2e} (|x| max {np.abs(ref).max():.2f})")
+            assert rel <= X_REL_BAR and mx <= X_ABS_BAR * max(1.0, np.abs(ref).max()), (tag, nl, seq, rel, mx)
+            if golden is not None and nl in (1, 9):   # the committed fixture holds layers 0 and 8
+                gref = golden[f"{tag}_x{seq}_l{nl - 1}"]
+                assert np.linalg.norm(got - gref) / np.linalg.norm(gref) <= X_REL_BAR
+    m.debug_set_layers(9)
+    res = m.match(px0, d0, px1, d1)
+    sim = m.debug_read(m.DEBUG_SIM, 0, n0, n1)
+    sref = it["sim"][0].double().numpy()
+    srel = np.abs(sim - sref).max() / np.abs(sref).max()
+    print(f"LG layers {tag}: sim max|d| {np.abs(sim - sref).max():.3e} / max|sim| {np.abs(sref).max():.1f} = {srel:.2e}")
+    assert srel <= SIM_REL_BAR
+    parity_report[f"lg_layers_{tag}"] = {"x_rel_worst": float(worst), "sim_rel": float(srel)}
+    return res
+
+
+@pytest.mark.parametrize("tag", ["n7x5", "n64x64", "n97x130"])
+def test_layers_on_committed_fixtures(lg, weights_dir, golden_dir, parity_report, tag):
+    g = np.load(os.path.join(golden_dir, "lightglue_selfcheck.npz"))
+    px0, px1 = _px(g[tag + "_kpts0"]), _px(g[tag + "_kpts1"])
+    d0, d1 = g[tag + "_desc0"].astype(np.float32), g[tag + "_desc1"].astype(np.float32)
+    res = _check_layers(lg, weights_dir, px0, d0, px1, d1, tag, parity_report, golden=g)
+    agree = (res.matches0 == g[tag + "_matches0"]).mean()
+    ds = np.abs(res.mscores0 - g[tag + "_mscores0"]).max()
+    print(f"LG {tag} vs committed vectors: agreement {agree:.4f} mscores max|d| {ds:.3e}")
+    parity_report[f"lg_layers_{tag}"].update(agreement=float(agree), mscores_maxd=float(ds))
+    assert agree >= 0.99 or (res.matches0 != g[tag + "_matches0"]).sum() <= 1
+    assert ds <= 2e-2
+
+
+@pytest.mark.parametrize("n0,n1,seed", [(600, 600, 31), (600, 17, 32), (33, 599, 33), (1, 1, 34)])
+def test_layers_full_size_and_ragged(lg, weights_dir, parity_report, n0, n1, seed):
+    k0, d0, k1, d1 = _random_sets(n0, n1, seed)
+    px0, px1 = _px(k0), _px(k1)
+    m_ref, s_ref, it = _oracle(weights_dir, px0, d0, px1, d1)
+    tag = f"n{n0}x{n1}"
+    res = _check_layers(lg, weights_dir, px0, d0, px1, d1, tag, parity_report, it=it)
+    agree = (res.matches0 == m_ref).mean()
+    ds = np.abs(res.mscores0 - s_ref).max()
+    print(f"LG {tag}: matched ref {int((m_ref >= 0).sum())} got {int((res.matches0 >= 0).sum())} agreement {agree:.4f} max|d| {ds:.3e}")
+    parity_report[f"lg_layers_{tag}"].update(agreement=float(agree), mscores_maxd=float(ds))
+    assert agree >= 0.99 or (res.matches0 != m_ref).sum() <= 1
+    assert ds <= 2e-2
+
+
+def test_layers_engine_max_1024(hip, weights_dir, parity_report):
+    """The reference engine's upper profile (scripts/rebuild_engines.sh:118): 1024 keypoints per image."""
+    m = _make_lg(weights_dir, 1024)
+    k0, d0, k1, d1 = _random_sets(1024, 1000, 41)
+    px0, px1 = _px(k0), _px(k1)
+    m_ref, s_ref, it = _oracle(weights_dir, px0, d0, px1, d1)
+    res = _check_layers(m, weights_dir, px0, d0, px1, d1, "n1024x1000", parity_report, layers=(1, 9), it=it)
+    agree = (res.matches0 == m_ref).mean()
+    ds = np.abs(res.mscores0 - s_ref).max()
+    print(f"LG n1024x1000: agreement {agree:.4f} max|d| {ds:.3e}")
+    parity_report["lg_layers_n1024x1000"].update(agreement=float(agree), mscores_maxd=float(ds))
+    assert agree >= 0.99 and ds <= 2e-2
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------------------
+# size-independent properties at full size
+# ------------------------------------------------------------------------------------------------------
+def test_translation_invariance(lg):
+    """Rotary self-attention sees relative positions only and cross-attention has no positional term: translating either
+    keypoint set (independently) leaves matches0 unchanged and mscores0 within fp16 noise."""
+    k0, d0, k1, d1 = _random_sets(600, 600, 51)
+    px0, px1 = _px(k0 * 0.8), _px(k1 * 0.8)
+    a = lg.match(px0, d0, px1, d1)
+    b = lg.match(px0 + np.float32([37.0, -11.0]), d0, px1 + np.float32([-64.0, 23.0]), d1)
+    agree = (a.matches0 == b.matches0).mean()
+    ds = np.abs(a.mscores0 - b.mscores0).max()
+    print(f"translation invariance: agreement {agree:.4f} max|d| {ds:.3e}")
+    assert agree >= 0.99 and ds <= 2e-2
+    assert (a.matches0 >= 0).sum() > 100
+
+
+def test_permutation_equivariance(lg):
+    """Permuting set 1 permutes matches0's values; permuting set 0 permutes matches0 / mscores0 themselves."""
+    k0, d0, k1, d1 = _random_sets(600, 577, 52)
+    px0, px1 = _px(k0), _px(k1)
+    a = lg.match(px0, d0, px1, d1)
+    rng = np.random.default_rng(52)
+    p1 = rng.permutation(577)
+    b = lg.match(px0, d0, px1[p1], d1[p1])
+    inv = np.empty_like(p1); inv[p1] = np.arange(577)
+    exp = np.where(a.matches0 >= 0, inv[np.maximum(a.matches0, 0)], -1)
+    agree1 = (b.matches0 == exp).mean()
+    p0 = rng.permutation(600)
+    c = lg.match(px0[p0], d0[p0], px1, d1)
+    agree0 = (c.matches0 == a.matches0[p0]).mean()
+    ds = max(np.abs(b.mscores0 - a.mscores0).max(), np.abs(c.mscores0 - a.mscores0[p0]).max())
+    print(f"permutation equivariance: set-1 {agree1:.4f} set-0 {agree0:.4f} max|d| {ds:.3e}")
+    assert agree1 >= 0.99 and agree0 >= 0.99 and ds <= 2e-2
+
+
+def test_padding_and_batch_slot_invariance(hip, lg, weights_dir):
+    """The same problem gives the same answer in a handle with a larger max_keypoints (more padding tokens to mask) and in
+    either slot of a two-pair batch next to an unrelated pair (ragged key masking, per-sequence lengths)."""
+    k0, d0, k1, d1 = _random_sets(300, 211, 53)
+    px0, px1 = _px(k0), _px(k1)
+    a = lg.match(px0, d0, px1, d1)
+    big = _make_lg(weights_dir, 1024)
+    b = big.match(px0, d0, px1, d1)
+    big.close()
+    np.testing.assert_array_equal(a.matches0, b.matches0)
+    np.testing.assert_allclose(a.mscores0, b.mscores0, atol=1e-6)
+    # batch: pair 0 = this problem, pair 1 = an unrelated one of different sizes (and the other way round)
+    o0, od0, o1, od1 = _random_sets(600, 555, 54)
+    mk = 600
+
+    def pack(sets):
+        kp = torch.zeros((4, mk, 3), dtype=torch.float32)
+        ds = torch.zeros((4, mk, 256), dtype=torch.float16)
+        n = torch.zeros(4, dtype=torch.int32)
+        for i, (k, d) in enumerate(sets):
+            kp[i, : len(k), :2] = torch.from_numpy(k); ds[i, : len(k)] = torch.from_numpy(d).half(); n[i] = len(k)
+        return kp.cuda(), n.cuda(), ds.cuda()
+
+    for order in (0, 1):
+        sets = [(px0, d0), (px1, d1), (_px(o0), od0), (_px(o1), od1)]
+        if order:
+            sets = sets[2:] + sets[:2]
+        kp, n, ds = pack(sets)
+        m0, ms0 = lg.match_batch_device(kp, n, ds)
+        torch.cuda.synchronize()
+        slot = 1 if order else 0
+        np.testing.assert_array_equal(m0[slot, :300].cpu().numpy(), a.matches0)
+        np.testing.assert_allclose(ms0[slot, :300].cpu().numpy(), a.mscores0, atol=1e-6)
+        assert (m0[slot, 300:].cpu().numpy() == -1).all()
+
+
+def test_counts_above_capacity_are_clamped(lg):
+    """A device-side count above max_keypoints (a caller bug) is clamped, not followed past the sequence stride."""
+    k0, d0, k1, d1 = _random_sets(600, 600, 55)
+    kp = torch.zeros((2, 600, 3), dtype=torch.float32)
+    kp[0, :, :2] = torch.from_numpy(_px(k0)); kp[1, :, :2] = torch.from_numpy(_px(k1))
+    ds = torch.stack([torch.from_numpy(d0).half(), torch.from_numpy(d1).half()])
+    ok = lg.match_batch_device(kp.cuda(), torch.tensor([600, 600], dtype=torch.int32).cuda(), ds.cuda())
+    torch.cuda.synchronize()
+    bad = lg.match_batch_device(kp.cuda(), torch.tensor([100000, 640], dtype=torch.int32).cuda(), ds.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(ok[0], bad[0]) and torch.allclose(ok[1], bad[1])
