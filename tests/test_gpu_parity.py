@@ -246,7 +246,7 @@ def test_superpoint_extract_vs_oracle_end_to_end(sp, weights_dir):
         bset = {(int(k[0]), int(k[1])) for k in ref["kp"]}
         iou = len(a & bset) / max(1, len(a | bset))
         print(f"e2e image {b}: n={len(f.keypoints)} ref n={len(ref['kp'])} keypoint IoU {iou:.4f}")
-        assert len(f.keypoints) == 600 and iou > 0.9
+        assert len(f.keypoints) == 600 and iou >= 0.98   # SURVEY 8(c); measured 0.993-0.997 (profiles/parity_report.json)
         sc = f.keypoints[:, 2]
         assert (np.diff(sc) <= 0).all()      # sortedness property (descending response)
     del fl, fr, f
@@ -446,7 +446,7 @@ def test_engine_max_keypoints_1024_and_odd_kitti_width(hip, weights_dir):
     b = {(round(float(k[0]), 2), int(k[1])) for k in ref["kp"]}
     iou = len(a & b) / len(a | b)
     print(f"1241x376 / 1024 kp: keypoint IoU vs oracle {iou:.4f}, max x {fl.keypoints[:, 0].max():.2f}")
-    assert iou > 0.9
+    assert iou >= 0.98
     assert np.allclose(fl.keypoints[:, 0] / np.float32(1241 / 1240), np.round(fl.keypoints[:, 0] / np.float32(1241 / 1240)), atol=1e-3)
     res = lg.match(fl.keypoints, fl.descriptors, fr.keypoints, fr.descriptors)
     d0, d1 = lg.descriptors_to_host(fl.descriptors), lg.descriptors_to_host(fr.descriptors)
