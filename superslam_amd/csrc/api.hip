@@ -993,6 +993,27 @@ extern "C" int sship_lg_weights_load(const char* path, sship_lg_weights** out) {
   if (int rc = require_device()) return rc;
   StateDict sd; std::string err;
   if (!load_safetensors(path, sd, err)) return fail(SSHIP_ERR_IO, err);
+  // The published checkpoint (superpoint_lightglue.pth) names the blocks self_attn.{i}.* / cross_attn.{i}.*; upstream's
+  // LightGlue.__init__ renames them to transformers.{i}.self_attn.* / .cross_attn.* at load time, which is also what
+  // matcher.state_dict() (the module the reference exports, utils/convert_lightglue_to_onnx.py:64-74) holds.  Accept both,
+  // and an optional "matcher." prefix (a state dict saved from a wrapper module).
+  {
+    StateDict renamed;
+    for (auto& kv : sd) {
+      std::string k = kv.first;
+      if (k.compare(0, 8, "matcher.") == 0) k = k.substr(8);
+      for (const char* blk : {"self_attn.", "cross_attn."}) {
+        const size_t bl = strlen(blk);
+        if (k.compare(0, bl, blk) == 0) {
+          const size_t dot = k.find('.', bl);
+          if (dot != std::string::npos && dot > bl && k.find_first_not_of("0123456789", bl) == dot)
+            k = "transformers." + k.substr(bl, dot - bl) + "." + std::string(blk, bl - 1) + k.substr(dot);
+        }
+      }
+      renamed[k] = std::move(kv.second);
+    }
+    sd.swap(renamed);
+  }
   sship_lg_weights* w = new sship_lg_weights();
   auto bail = [&](int rc, const std::string& m) { lg_weights_free(w); return fail(rc, m); };
   auto lin = [&](const std::string& name, int cout, int cin, ConvW& dst, const std::vector<int>* map = nullptr,

@@ -113,6 +113,29 @@ def make_lightglue_weights(seed: int = 1, residual_gain: float = 0.05, assign_ga
     return sd
 
 
+def normalize_lightglue_keys(sd: dict) -> dict:
+    """Raw upstream checkpoint names -> module names: ``self_attn.{i}.*`` -> ``transformers.{i}.self_attn.*`` (and
+    cross_attn), optional ``matcher.`` prefix dropped - the rename upstream's LightGlue.__init__ applies at load time
+    (checkpoint key layout).  The C loader (sship_lg_weights_load) applies the same rule."""
+    import re
+
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("matcher."):
+            k = k[len("matcher."):]
+        k = re.sub(r"^(self_attn|cross_attn)\.(\d+)\.", lambda m: f"transformers.{m.group(2)}.{m.group(1)}.", k)
+        out[k] = v
+    return out
+
+
+def to_raw_checkpoint_keys(sd: dict) -> dict:
+    """Inverse of normalize_lightglue_keys (tests: a state dict in the published checkpoint's layout)."""
+    import re
+
+    return {re.sub(r"^transformers\.(\d+)\.(self_attn|cross_attn)\.", lambda m: f"{m.group(2)}.{m.group(1)}.", k): v
+            for k, v in sd.items()}
+
+
 def save_safetensors(sd: dict, path: str) -> None:
     from safetensors.torch import save_file
 

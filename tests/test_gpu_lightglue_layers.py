@@ -267,3 +267,25 @@ def test_counts_above_capacity_are_clamped(lg):
     bad = lg.match_batch_device(kp.cuda(), torch.tensor([100000, 640], dtype=torch.int32).cuda(), ds.cuda())
     torch.cuda.synchronize()
     assert torch.equal(ok[0], bad[0]) and torch.allclose(ok[1], bad[1])
+
+
+def test_loader_accepts_the_raw_checkpoint_key_layout(hip, lg, weights_dir, tmp_path):
+    """self_attn.{i}.* / cross_attn.{i}.* (the published .pth layout) load to the same matcher as the module names."""
+    from superslam_amd import LightGlue
+    from superslam_amd.weights import save_safetensors, to_raw_checkpoint_keys
+
+    raw_path = str(tmp_path / "lg_raw_names.safetensors")
+    save_safetensors(to_raw_checkpoint_keys(weights_dir["lg"]), raw_path)
+    m = LightGlue(raw_path, W, HH, max_keypoints=600, max_pairs=1)
+    assert m.initialize(), m.last_error
+    k0, d0, k1, d1 = _random_sets(200, 180, 61)
+    a = lg.match(_px(k0), d0, _px(k1), d1)
+    b = m.match(_px(k0), d0, _px(k1), d1)
+    np.testing.assert_array_equal(a.matches0, b.matches0)
+    np.testing.assert_array_equal(a.mscores0, b.mscores0)
+    assert (a.matches0 >= 0).sum() > 20
+    m.close()
+    broken = {k: v for k, v in to_raw_checkpoint_keys(weights_dir["lg"]).items() if k != "cross_attn.3.to_v.weight"}
+    save_safetensors(broken, raw_path)
+    bad = LightGlue(raw_path, W, HH, max_keypoints=600)
+    assert not bad.initialize() and "cross_attn.to_v.weight" in bad.last_error   # fails loudly, names the tensor

@@ -399,3 +399,17 @@ def test_unmasked_padding_breaks_the_bars(golden_dir):
     ds = float(np.abs(s - g[tag + "_mscores0"]).max())
     print(f"unmasked padding: agreement {agree:.3f} max|d| {ds:.3f}")
     assert agree < GPU_AGREEMENT_BAR or ds > GPU_MSCORE_BAR
+
+
+def test_raw_checkpoint_key_layout_round_trip():
+    """The published checkpoint names blocks self_attn.{i}.* / cross_attn.{i}.*; upstream renames them at load."""
+    from superslam_amd.weights import normalize_lightglue_keys, to_raw_checkpoint_keys
+
+    sd = make_lightglue_weights(1)
+    raw = to_raw_checkpoint_keys(sd)
+    assert "self_attn.0.Wqkv.weight" in raw and "cross_attn.8.to_qk.bias" in raw and "posenc.Wr.weight" in raw
+    assert not any(k.startswith("transformers.") for k in raw)
+    back = normalize_lightglue_keys({("matcher." + k if i % 2 else k): v for i, (k, v) in enumerate(raw.items())})
+    assert set(back) == set(sd)
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    assert normalize_lightglue_keys({"self_attn.12.ffn.0.weight": 1}) == {"transformers.12.self_attn.ffn.0.weight": 1}
