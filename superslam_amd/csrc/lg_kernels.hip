@@ -391,22 +391,26 @@ constexpr int kFfnLd = 520;
 #define SSHIP_FFN_ABL 0
 #endif
 typedef float f2_t __attribute__((ext_vector_type(2)));
-// exact-erf GELU on two values with packed fp32 math: gelu(y) = y Phi(y) = max(y, 0) - h, h = 0.5 |y| erfc(|y| / sqrt 2),
-// erfc(|y|/sqrt 2) = p(t) exp(-y^2/2), t = 1 / (1 + 0.3275911 |y| / sqrt 2)  (Abramowitz & Stegun 7.1.26, |err| <= 1.5e-7;
-// the 0.5 is folded into the polynomial).  2 transcendentals + ~8 packed ops per value.
+// GELU (exact-erf form, nn.GELU()) on two values.  gelu(y) = y Phi(y) = y sigmoid(g(y)) with g = logit(Phi), an odd function:
+// g(y) = y Q(y^2), Q a degree-4 polynomial fitted (minimax on the relative error over |y| <= 12, scripts/fit_gelu.py) to
+//   max |gelu_approx - y Phi(y)| = 7.0e-6,  relative 4.4e-5 where |gelu| >= 0.05
+// i.e. under a fifth of half an fp16 ulp of the result, which is rounded to fp16 right after (tests/test_lightglue_known_answers.py
+// evaluates these very constants in fp32 against erf).  Q > 0 everywhere, so the form saturates correctly (y -> +inf: y,
+// y -> -inf: -0).  Cost per pair of values: 8 packed fp32 ops + 2 v_exp + 2 v_rcp; the Abramowitz-Stegun erfc form it
+// replaces (|err| 1.5e-7) took 16 packed ops + 4 transcendentals + 2 max, and the GELU phase is VALU-issue bound.
+// The coefficients carry the factor -log2(e) so that sigmoid(g) = 1 / (1 + exp2(y q(y^2))).
+constexpr float kGeluQ0 = -2.301893292e+00f, kGeluQ1 = -1.054467824e-01f, kGeluQ2 = 4.423903354e-04f, kGeluQ3 = 7.747288073e-05f,
+                kGeluQ4 = -2.787147429e-06f;
 __device__ __forceinline__ f2_t gelu2(f2_t y) {
-  const f2_t ay = {fabsf(y[0]), fabsf(y[1])};
-  const f2_t d = ay * 0.23164189f + 1.0f;
-  const f2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  f2_t p = t * 0.5307027145f + -0.7265760135f;
-  p = p * t + 0.7107068705f;
-  p = p * t + -0.142248368f;
-  p = p * t + 0.127414796f;
-  const f2_t ex = ay * ay * -0.72134752f;
-  const f2_t e = {__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
-  const f2_t h = p * t * ay * e;
-  const f2_t pos = {fmaxf(y[0], 0.f), fmaxf(y[1], 0.f)};
-  return pos - h;
+  const f2_t s = y * y;
+  f2_t q = s * kGeluQ4 + kGeluQ3;
+  q = q * s + kGeluQ2;
+  q = q * s + kGeluQ1;
+  q = q * s + kGeluQ0;
+  const f2_t t = y * q;
+  const f2_t d = {1.0f + __builtin_amdgcn_exp2f(t[0]), 1.0f + __builtin_amdgcn_exp2f(t[1])};
+  const f2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return y * r;
 }
 struct FfnTail {
   int ntiles;                               // token tiles of the launch (the kernel is persistent: tile = blockIdx.x + k gridDim.x)
@@ -801,6 +805,446 @@ static hipError_t launch_ffn(int nt, int tokens, hipStream_t s, A... args) {
   // end (1.25 tiles per CU at 32 pairs, single tile buffer) and no longer fits the registers: not instantiated.
   return nt == 1 ? launch_ffn_nt<NEXT_MT, HEADS, 1, false>(tokens, s, args...) : launch_ffn_nt<NEXT_MT, HEADS, 2, false>(tokens, s, args...);
 }
+// ---------------------------------------------------------------------------------------------------
+// k_lg_ffn4: the same fused block with FOUR waves per workgroup and TWO workgroups per CU (throughput batches).
+//
+// The 8-wave kernel above runs one workgroup per CU whose waves move through  ffn.0 -> LayerNorm -> GELU -> ffn.3 ->
+// residual -> projection -> epilogue  in lock-step: its phase trace (profiles/r01_v12_ffn_phase_trace.txt) shows the
+// matrix pipe busy for ~16 k of a 56-71 k-clock tile - it idles whenever all eight waves are in a VALU / LDS / store phase.
+// Here a workgroup is 4 waves (one per SIMD) that own a 64-token tile on their own - wave w computes 128 ffn.0 rows,
+// 64 ffn.3 rows and two 32*NEXT_MT-row blocks of the fused projection - and keeps ONE tile buffer (66.5 KB), so two
+// workgroups fit a CU (2 x 75.8 KB of LDS, 2 waves per SIMD).  The two workgroups of a CU are independent, drift apart
+// and run complementary phases most of the time: one wave's MFMA stream rides beside the other's GELU / epilogue VALU
+// on the same SIMD (MI355X_MICROARCH.md: the MFMA and VALU pipes of a SIMD are separate).  Per-wave register tiles are
+// twice as large (4 M-tiles x 2 N-tiles for ffn.0), so every LDS B-fragment read feeds twice as many MFMAs as before.
+// Weight bytes streamed from L2 per token are unchanged (1.18 MB per 64-token tile).
+//   * the rotary table of the q / k epilogue is prefetched into registers BEFORE the projection's MFMA loop (it was 8
+//     dependent L2 round trips per M-tile inside the epilogue, the longest phase of the CrossBlock kernel);
+//   * q / k rows are written as 16-byte fragment units: v_permlane32_swap pairs the two half-waves' 4-channel quads
+//     (they were 8-byte stores);
+//   * the residual operand is read from the x half of the LDS tile before it is overwritten (no global re-read);
+//   * the next tile's LDS-DMA is issued after the last epilogue: its latency is covered by the other workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int NEXT_MT, bool HEADS, bool PROJ>
+__global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
+                                                    const float* __restrict__ b0, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const _Float16* __restrict__ w3p,
+                                                    const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
+  constexpr int NT = 2, NTOK = 64;
+  extern __shared__ __attribute__((aligned(16))) char ffn_smem[];
+  _Float16* s_x = reinterpret_cast<_Float16*>(ffn_smem);                            // [NTOK][kFfnLd]
+  float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_x + NTOK * kFfnLd);     // [8][NTOK]: per-wave sums, sums of squares
+  float* s_par = reinterpret_cast<float*>(s_red) + 8 * NTOK;                         // [b0 512 | gamma 512 | beta 512 | b3 256]
+  float* s_pb = s_par + 1792;                                                        // bias of the fused projection [<= 768]
+  for (int i = threadIdx.x; i < (PROJ ? 0 : 1792); i += 256)
+    s_par[i] = i < 512 ? b0[i] : i < 1024 ? gamma[i - 512] : i < 1536 ? beta[i - 1024] : b3[i - 1536];
+  // LDS, not global: a global load in the epilogue sits behind the epilogue's own stores in the in-order vmcnt queue
+  // (the first version of this kernel spent 16 k clocks per CrossBlock tile there)
+  if constexpr (NEXT_MT > 0 && HEADS)
+    for (int i = threadIdx.x; i < NEXT_MT * 256; i += 256) s_pb[i] = tail.proj.bias[i];
+  auto stage_tile = [&](int tile, int wave, int lane) {
+    const size_t tt = (size_t)tile * NTOK;
+#pragma unroll
+    for (int k = 0; k < NTOK / 4; ++k) {
+      const int tok = wave + 4 * k;
+      const _Float16* gsrc = (lane < 32 ? x + (tt + tok) * 256 + lane * 8 : ctx + (tt + tok) * 256 + (lane - 32) * 8);
+      const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(s_x + tok * kFfnLd));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  const int tile0 = blockIdx.x;
+  if (tile0 >= tail.ntiles) return;
+  stage_tile(tile0, threadIdx.x >> 6, threadIdx.x & 63);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int it = 0;
+#pragma unroll 1
+  for (int tile = tile0; tile < tail.ntiles; tile += gridDim.x, ++it) {
+  const bool has_next = tile + (int)gridDim.x < tail.ntiles;
+  const size_t t0 = (size_t)tile * NTOK;
+  int zero = 0;
+  asm volatile("" : "+s"(zero));  // keeps loop-invariant weight / parameter loads inside the iteration (see k_lg_ffn)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const _Float16 *w0q = w0p + zero, *w3q = w3p + zero;
+  const float *b0q = s_par + zero, *gq = s_par + 512 + zero, *beq = s_par + 1024 + zero, *b3q = s_par + 1536 + zero;
+  IgemmArgs pj = tail.proj;
+  pj.wpack += zero; pj.bias += zero;
+  const float* mwq = tail.match_w + zero;
+  const _Float16* bfp = s_x + j * kFfnLd + hh * 8;  // B fragment of N-tile n, k-step ks: bfp + n*32*kFfnLd + ks*16
+  auto stamp = [&](int slot) {
+    if (tail.trace && it == 1 && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
+  };
+  stamp(0);
+  if constexpr (!PROJ) {
+  // ---- ffn.0 : rows [128 wave, +128) x 64 tokens, K = 512.  Fragment f = 2 * (64-row block) + m-tile ----
+  f16x_t acc[4][NT];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][n][r] = 0.f;
+  {
+    // Weight fragments stream from L2 through a ring of R0 k-steps of registers: the load of k-step ks + R0 - 1 is issued
+    // before the MFMAs of k-step ks, so every fragment has (R0 - 1) x 8 MFMAs (~1 k clocks) to arrive - an L2 hit under load
+    // takes 600-900 clocks, and the two-group scheme of k_lg_ffn (one group = 512 clocks of cover) left this kernel's MFMA
+    // phases at half rate.  The token-tile B fragments are read from LDS one k-step ahead.
+    constexpr int R0 = 4;
+    const _Float16* wp = w0q + (size_t)(2 * wave) * (32 * 2 * 512) + lane * 8;  // packed [cb = 2 wave + (f >> 1)][k16][mt = f & 1][lane][8]
+    auto frag = [&](int ks, int f) { return *reinterpret_cast<const h8_t*>(wp + (size_t)(f >> 1) * (32 * 2 * 512) + (ks * 2 + (f & 1)) * 512); };
+    h8_t ab[R0][4], bf[2][NT];
+#pragma unroll
+    for (int i = 0; i < R0 - 1; ++i)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) ab[i][f] = frag(i, f);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      if (ks + R0 - 1 < 32) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) ab[(ks + R0 - 1) % R0][f] = frag(ks + R0 - 1, f);
+      }
+      if (ks + 1 < 32) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[(ks + 1) & 1][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + (ks + 1) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the loads above stay ABOVE this k-step's MFMAs
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[f][n] = mfma32(ab[ks % R0][f], bf[ks & 1][n], acc[f][n]);
+    }
+  }
+  stamp(1);
+  // ---- bias, LayerNorm(512) statistics (regs -> lane^32 -> the 4 waves through LDS) ----
+  float sum[NT], sq[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { sum[n] = 0.f; sq[n] = 0.f; }
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *reinterpret_cast<const float4*>(b0q + wave * 128 + f * 32 + hh * 4 + g * 8);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[f][n][4 * g + 0] += bv.x; acc[f][n][4 * g + 1] += bv.y; acc[f][n][4 * g + 2] += bv.z; acc[f][n][4 * g + 3] += bv.w;
+        sum[n] += (acc[f][n][4 * g + 0] + acc[f][n][4 * g + 1]) + (acc[f][n][4 * g + 2] + acc[f][n][4 * g + 3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq[n] = fmaf(acc[f][n][4 * g + e], acc[f][n][4 * g + e], sq[n]);
+      }
+    }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    sum[n] += __shfl_xor(sum[n], 32, 64);
+    sq[n] += __shfl_xor(sq[n], 32, 64);
+    if (hh == 0) { s_red[wave][n * 32 + j] = sum[n]; s_red[4 + wave][n * 32 + j] = sq[n]; }
+  }
+  // the residual operand (this lane's ffn.3 rows of x) comes from the x half of the tile, before GELU overwrites it
+  h4_t xres[2][4][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        xres[m][g][n] = *reinterpret_cast<const h4_t*>(s_x + (n * 32 + j) * kFfnLd + wave * 64 + m * 32 + hh * 4 + g * 8);
+  __syncthreads();  // statistics complete; every wave has finished reading the input tile
+  float mean[NT], rstd[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    float t = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { t += s_red[w][n * 32 + j]; q += s_red[4 + w][n * 32 + j]; }
+    mean[n] = t * (1.0f / 512.0f);
+    rstd[n] = __builtin_amdgcn_rsqf(fmaxf(q * (1.0f / 512.0f) - mean[n] * mean[n], 0.f) + 1e-5f);
+  }
+  stamp(2);
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = wave * 128 + f * 32 + hh * 4 + g * 8;
+      const float4 gv = *reinterpret_cast<const float4*>(gq + c);
+      const float4 be = *reinterpret_cast<const float4*>(beq + c);
+      const f2_t g01 = {gv.x, gv.y}, g23 = {gv.z, gv.w}, b01 = {be.x, be.y}, b23 = {be.z, be.w};
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const f2_t a01 = {acc[f][n][4 * g + 0], acc[f][n][4 * g + 1]}, a23 = {acc[f][n][4 * g + 2], acc[f][n][4 * g + 3]};
+        const f2_t o01 = gelu2((a01 - mean[n]) * rstd[n] * g01 + b01);
+        const f2_t o23 = gelu2((a23 - mean[n]) * rstd[n] * g23 + b23);
+        *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o01[0], o01[1], o23[0], o23[1]);
+      }
+    }
+  stamp(3);
+  __syncthreads();  // hidden tile complete
+  stamp(4);
+  // ---- ffn.3 : rows [64 wave, +64) x 64 tokens, K = 512, + residual ----
+  f16x_t ac2[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ac2[m][n][r] = 0.f;
+  {
+    constexpr int R3 = 8;
+    const _Float16* wp = w3q + (size_t)(2 * wave) * (32 * 512) + lane * 8;  // packed [cb = 2 wave + m][k16][mt = 0][lane][8]
+    h8_t a3[R3][2], bf[2][NT];
+#pragma unroll
+    for (int i = 0; i < R3 - 1; ++i)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a3[i][m] = *reinterpret_cast<const h8_t*>(wp + (size_t)m * (32 * 512) + i * 512);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      if (ks + R3 - 1 < 32) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          a3[(ks + R3 - 1) % R3][m] = *reinterpret_cast<const h8_t*>(wp + (size_t)m * (32 * 512) + (ks + R3 - 1) * 512);
+      }
+      if (ks + 1 < 32) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[(ks + 1) & 1][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + (ks + 1) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ac2[m][n] = mfma32(a3[ks % R3][m], bf[ks & 1][n], ac2[m][n]);
+    }
+  }
+  stamp(5);
+  if constexpr (NEXT_MT > 0) __syncthreads();  // all waves are done reading the hidden tile: s_x gets the new x
+  // x <- x + ffn.3(...) + b3: lane (j, hh) holds channels 4 hh + 8 g .. + 3 of token j; v_permlane32_swap pairs the two
+  // half-waves' quads so that every lane writes whole 8-channel (16-byte) units to global memory and to the LDS tile
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      unsigned lo[4], hi[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(b3q + wave * 64 + m * 32 + hh * 4 + g * 8);
+        const h4_t o = xres[m][g][n];
+        const h2_t p01 = {(_Float16)((float)o[0] + (ac2[m][n][4 * g + 0] + bv.x)), (_Float16)((float)o[1] + (ac2[m][n][4 * g + 1] + bv.y))};
+        const h2_t p23 = {(_Float16)((float)o[2] + (ac2[m][n][4 * g + 2] + bv.z)), (_Float16)((float)o[3] + (ac2[m][n][4 * g + 3] + bv.w))};
+        lo[g] = __builtin_bit_cast(unsigned, p01);
+        hi[g] = __builtin_bit_cast(unsigned, p23);
+      }
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(lo[2 * gp], lo[2 * gp + 1], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(hi[2 * gp], hi[2 * gp + 1], false, false);
+        const uint4 unit = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        const int c = wave * 64 + m * 32 + (2 * gp + hh) * 8;
+        *reinterpret_cast<uint4*>(x + (t0 + n * 32 + j) * 256 + c) = unit;
+        if constexpr (NEXT_MT > 0) *reinterpret_cast<uint4*>(s_x + (n * 32 + j) * kFfnLd + c) = unit;
+      }
+    }
+  stamp(6);
+  }  // !PROJ
+  if constexpr (NEXT_MT > 0) {
+    __syncthreads();
+    stamp(7);
+    // ---- fused next projection: two passes; pass p = row block cb = wave + 4 p of the tile-interleaved packing
+    // (block cb holds M-tile m = rows (8 m + cb) * 32 .. + 31: one tile of each 256-row segment), K = 256 ----
+    const int NP = pj.np, nt32 = NP >> 5;
+    const int rope_segs = pj.flags & 0xf;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const int cb = wave + 4 * pass;
+      f16x_t ac3[NEXT_MT][NT];
+#pragma unroll
+      for (int m = 0; m < NEXT_MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ac3[m][n][r] = 0.f;
+      // rotary (cos, sin) quads of this lane's q / k rows: requested here, consumed after the MFMA loop.  The q and the k
+      // tile of a block cover the same head-local channels ((8 m + cb) * 32 mod 64 does not depend on m): one set serves both.
+      float4 cs[4][NT];
+      if constexpr (HEADS) {
+        if (rope_segs > 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              cs[g][n] = *reinterpret_cast<const float4*>(pj.aux + (t0 + n * 32 + j) * 64 + ((cb * 32) & 63) + hh * 4 + g * 8);
+        }
+      }
+      const _Float16* wp = pj.wpack + (size_t)cb * (16 * NEXT_MT * 512) + lane * 8;  // [cb][k16][mt][lane][8]
+      constexpr int VMASK = HEADS ? (1 << (NEXT_MT - 1)) : 0;  // the V tile runs with swapped operands (see k_lg_ffn)
+      constexpr int RT = NEXT_MT >= 3 ? 4 : 5;
+      h8_t at[RT][NEXT_MT], bf[2][NT];
+#pragma unroll
+      for (int i = 0; i < RT - 1; ++i)
+#pragma unroll
+        for (int m = 0; m < NEXT_MT; ++m) at[i][m] = *reinterpret_cast<const h8_t*>(wp + (i * NEXT_MT + m) * 512);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + RT - 1 < 16) {
+#pragma unroll
+          for (int m = 0; m < NEXT_MT; ++m) at[(ks + RT - 1) % RT][m] = *reinterpret_cast<const h8_t*>(wp + ((ks + RT - 1) * NEXT_MT + m) * 512);
+        }
+        if (ks + 1 < 16) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[(ks + 1) & 1][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + (ks + 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NEXT_MT; ++m) {
+          const h8_t a = at[ks % RT][m];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if ((VMASK >> m) & 1) ac3[m][n] = mfma32(bf[ks & 1][n], a, ac3[m][n]);
+            else ac3[m][n] = mfma32(a, bf[ks & 1][n], ac3[m][n]);
+          }
+        }
+      }
+      stamp(8 + pass);
+      if constexpr (HEADS) {
+#pragma unroll
+        for (int m = 0; m < NEXT_MT; ++m) {
+          const int R0 = (m * 8 + cb) * 32;  // first output row of this M-tile
+          const int hd = (R0 >> 6) & 3;
+          if ((VMASK >> m) & 1) {
+            const int mth = (R0 >> 5) & 1;  // 32-channel half of the head
+            const float bv = s_pb[R0 + j];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const size_t token = t0 + n * 32;
+              const int sq = (int)(token / NP), kt = (int)(token - (size_t)sq * NP) >> 5;
+              _Float16* dst = static_cast<_Float16*>(pj.out2) + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048 + lane * 8;
+#pragma unroll
+              for (int kk = 0; kk < 2; ++kk) {
+                h8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)(ac3[m][n][8 * kk + e] + bv);
+                *reinterpret_cast<h8_t*>(dst + (kk * 2 + mth) * 512) = o;
+              }
+            }
+          } else {
+            // q / k (or the shared qk of CrossBlock): bias, rotary on interleaved pairs, fp16, then lane^32 pairing so that
+            // every lane owns whole 16-byte fragment units: unit u = d / 8 -> [kstep u / 2][lane' = (u & 1) * 32 + token % 32][8]
+            const int seg = R0 >> 8;
+            _Float16* base = static_cast<_Float16*>(seg == 0 ? pj.out0 : pj.out1);
+            const bool roped = seg < rope_segs;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const size_t token = t0 + n * 32;
+              const int sq = (int)(token / NP), kt = (int)(token - (size_t)sq * NP) >> 5;
+              _Float16* dst = base + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048;
+              unsigned lo[4], hi[4];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(s_pb + R0 + hh * 4 + g * 8);
+                float v0 = ac3[m][n][4 * g + 0] + bv.x, v1 = ac3[m][n][4 * g + 1] + bv.y;
+                float v2 = ac3[m][n][4 * g + 2] + bv.z, v3 = ac3[m][n][4 * g + 3] + bv.w;
+                if (roped) {
+                  const float4 c = cs[g][n];
+                  const float r0 = v0 * c.x - v1 * c.y, r1 = v1 * c.x + v0 * c.y;
+                  const float r2 = v2 * c.z - v3 * c.w, r3 = v3 * c.z + v2 * c.w;
+                  v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+                }
+                const h2_t p01 = {(_Float16)v0, (_Float16)v1}, p23 = {(_Float16)v2, (_Float16)v3};
+                lo[g] = __builtin_bit_cast(unsigned, p01);
+                hi[g] = __builtin_bit_cast(unsigned, p23);
+              }
+#pragma unroll
+              for (int gp = 0; gp < 2; ++gp) {
+                // swap(A, B): A' = {A.lo-lanes, B.lo-lanes}, B' = {A.hi-lanes, B.hi-lanes}.  With A = quad g = 2 gp and
+                // B = quad 2 gp + 1, lane hh = 0 ends up with the whole unit of quad 2 gp, lane hh = 1 with that of 2 gp + 1.
+                const auto s0 = __builtin_amdgcn_permlane32_swap(lo[2 * gp], lo[2 * gp + 1], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(hi[2 * gp], hi[2 * gp + 1], false, false);
+                const uint4 unit = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                const int u = ((R0 & 63) >> 3) + 2 * gp + hh;
+                *reinterpret_cast<uint4*>(dst + (u >> 1) * 512 + (((u & 1) << 5) + j) * 8) = unit;
+              }
+            }
+          }
+        }
+      } else {
+        // plain fp16 rows (final_proj): block cb = rows cb * 32 .. + 31 (NEXT_MT = 1, not interleaved)
+        EpiF16<false, false>::template run<NEXT_MT, NT>(pj, ac3, 0, (int)(t0 >> 5), j, cb * NEXT_MT * 32, hh);
+      }
+    }
+    if (tail.logsig) {  // matchability head of the last block: one wave per 16 tokens
+#pragma unroll 1
+      for (int tk = wave * (NTOK / 4); tk < (wave + 1) * (NTOK / 4); ++tk) {
+        const h4_t v = *reinterpret_cast<const h4_t*>(s_x + tk * kFfnLd + lane * 4);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d += (float)v[e] * mwq[lane * 4 + e];
+        const float z = wave_sum(d) + tail.match_b;
+        if (lane == 0) tail.logsig[t0 + tk] = fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
+      }
+    }
+  }
+  stamp(10);
+  if (has_next) {
+    __syncthreads();  // every wave has finished with the tile buffer
+    stage_tile(tile + gridDim.x, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  stamp(11);
+  }  // tile loop
+}
+template <int NEXT_MT, bool HEADS, bool PROJ, typename... A>
+static hipError_t launch_ffn4(int tokens, hipStream_t s, A... args) {
+  constexpr size_t smem = (size_t)64 * kFfnLd * 2 + 8 * 64 * 4 + (1792 + 768) * 4;  // 78,848 B: two workgroups per CU
+  static_assert(2 * smem <= 163840, "two workgroups must fit the CU's LDS");
+  auto kern = k_lg_ffn4<NEXT_MT, HEADS, PROJ>;
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (attr_rc != hipSuccess) return attr_rc;
+  const int ntiles = tokens / 64;
+  hipLaunchKernelGGL(kern, dim3(ntiles < 2 * cu_count() ? ntiles : 2 * cu_count()), dim3(256), smem, s, args...);
+  return hipGetLastError();
+}
+// the 4-wave kernel serves throughput batches (at least one 64-token tile per workgroup slot); SUPERSLAM_HIP_FFN=8 keeps
+// the 8-wave kernel everywhere (A/B runs)
+static bool use_ffn4(int tokens) {
+  static const int env = getenv("SUPERSLAM_HIP_FFN") ? atoi(getenv("SUPERSLAM_HIP_FFN")) : 0;
+  if (env == 8) return false;
+  if (env == 4) return tokens % 64 == 0;
+  return tokens % 64 == 0 && tokens / 64 >= 2 * cu_count();
+}
+
+static bool trace_on_is8() { return false; }
+// SSHIP_FFN_TRACE=1 with the 4-wave kernel: mean shader-clock duration of every phase of a workgroup's second tile
+static void ffn4_trace_report(unsigned long long* dev, int nwg, int next_mt, hipStream_t s) {
+  std::vector<unsigned long long> h((size_t)nwg * 8 * 12);
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost);
+  // stamps: 0 start, 1 ffn.0 done, 2 stats+barrier, 3 GELU, 4 barrier, 5 ffn.3, 6 residual, 7 barrier, 8 proj pass 0 MFMA,
+  // 9 (epilogue 0 +) proj pass 1 MFMA, 10 epilogue 1 (+ matchability), 11 next-tile DMA + barriers
+  static const char* names[11] = {"ffn.0", "stats+barrier", "GELU", "barrier", "ffn.3", "barrier+residual", "barrier", "proj0 MFMA",
+                                  "epi0+proj1 MFMA", "epi1", "restage"};
+  double sum[11] = {0}; long cnt = 0;
+  for (int w = 0; w < nwg * 8; ++w) {
+    const unsigned long long* t = h.data() + (size_t)w * 12;
+    if (!t[0] || !t[11]) continue;
+    for (int i = 0; i < 11; ++i) {
+      unsigned long long a = t[i], b = t[i + 1];
+      if (!b) b = a;  // phases a variant does not have
+      sum[i] += (double)(b > a ? b - a : 0);
+    }
+    ++cnt;
+  }
+  if (!cnt) return;
+  fprintf(stderr, "[ffn4 trace next_mt=%d, %ld waves]", next_mt, cnt);
+  double tot = 0;
+  for (int i = 0; i < 11; ++i) { fprintf(stderr, " %s=%.0f", names[i], sum[i] / cnt); tot += sum[i] / cnt; }
+  fprintf(stderr, " | tile=%.0f clk\n", tot);
+}
 // next == nullptr: plain FFN.  Otherwise the projection `next` (packed with ct = 32 * next_mt rows per wave) runs on
 // the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
 void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
@@ -816,8 +1260,8 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   static unsigned long long* trace_buf = nullptr;
   const int trace_wg = t.ntiles < cu_count() ? t.ntiles : cu_count();
   if (trace_on) {
-    if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)cu_count() * 8 * 12 * 8);
-    (void)hipMemsetAsync(trace_buf, 0, (size_t)cu_count() * 8 * 12 * 8, s);
+    if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)2 * cu_count() * 8 * 12 * 8);
+    (void)hipMemsetAsync(trace_buf, 0, (size_t)2 * cu_count() * 8 * 12 * 8, s);
     t.trace = trace_buf;
   }
   if (!next) {
@@ -830,6 +1274,14 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
   const int mt = next->cout / 256;  // rows per wave / 32: 768 -> 3, 512 -> 2, 256 -> 1
+  if (use_ffn4(tokens) && !trace_on_is8()) {
+    t.ntiles = tokens / 64;
+    if (heads && mt == 3) (void)launch_ffn4<3, true, false>(tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    else if (heads && mt == 2) (void)launch_ffn4<2, true, false>(tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    else (void)launch_ffn4<1, false, false>(tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    if (trace_on) ffn4_trace_report(trace_buf, t.ntiles < 2 * cu_count() ? t.ntiles : 2 * cu_count(), mt, s);
+    return;
+  }
   if (heads && mt == 3) (void)launch_ffn<3, true>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
   else if (heads && mt == 2) (void)launch_ffn<2, true>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
   else (void)launch_ffn<1, false>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
@@ -850,6 +1302,10 @@ hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int ro
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   const _Float16* nh = nullptr;
   const float* nf = nullptr;
+  if (use_ffn4(tokens)) {
+    t.ntiles = tokens / 64;
+    return launch_ffn4<3, true, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t);
+  }
   return nt == 1 ? launch_ffn_nt<3, true, 1, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t)
                  : launch_ffn_nt<3, true, 2, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t);
 }

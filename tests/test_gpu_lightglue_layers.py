@@ -197,7 +197,7 @@ def test_translation_invariance(lg):
     agree = (a.matches0 == b.matches0).mean()
     ds = np.abs(a.mscores0 - b.mscores0).max()
     print(f"translation invariance: agreement {agree:.4f} max|d| {ds:.3e}")
-    assert agree >= 0.99 and ds <= 2e-2
+    assert agree >= 0.99 and ds <= 3e-2    # two fp16 runs with different rotary values: each within 2e-2 of the oracle
     assert (a.matches0 >= 0).sum() > 100
 
 
@@ -217,7 +217,7 @@ def test_permutation_equivariance(lg):
     agree0 = (c.matches0 == a.matches0[p0]).mean()
     ds = max(np.abs(b.mscores0 - a.mscores0).max(), np.abs(c.mscores0 - a.mscores0[p0]).max())
     print(f"permutation equivariance: set-1 {agree1:.4f} set-0 {agree0:.4f} max|d| {ds:.3e}")
-    assert agree1 >= 0.99 and agree0 >= 0.99 and ds <= 2e-2
+    assert agree1 >= 0.99 and agree0 >= 0.99 and ds <= 3e-2
 
 
 def test_padding_and_batch_slot_invariance(hip, lg, weights_dir):
@@ -289,3 +289,52 @@ def test_loader_accepts_the_raw_checkpoint_key_layout(hip, lg, weights_dir, tmp_
     save_safetensors(broken, raw_path)
     bad = LightGlue(raw_path, W, HH, max_keypoints=600)
     assert not bad.initialize() and "cross_attn.to_v.weight" in bad.last_error   # fails loudly, names the tensor
+
+
+def test_throughput_batch_kernels_match_latency_kernels(hip, lg, weights_dir, parity_report):
+    """A 64-pair batch runs the throughput kernels (4-wave FFN with two workgroups per CU, 2-tile attention); single calls
+    run the latency kernels.  Same arithmetic, different tiling: every pair of the batch must agree with its single-call
+    result (and through it with the oracle), including ragged lengths inside the batch."""
+    P, mk = 64, 600
+    big = _make_lg(weights_dir, mk, P)
+    rng = np.random.default_rng(7)
+    kp = torch.zeros((2 * P, mk, 3), dtype=torch.float32)
+    ds = torch.zeros((2 * P, mk, 256), dtype=torch.float16)
+    n = torch.zeros(2 * P, dtype=torch.int32)
+    sets = []
+    for p in range(P):
+        n0, n1 = (600, 600) if p % 4 else (int(rng.integers(1, 601)), int(rng.integers(1, 601)))
+        k0, d0, k1, d1 = _random_sets(n0, n1, 1000 + p)
+        sets.append((_px(k0), d0, _px(k1), d1))
+        for i, (k, d) in enumerate(((sets[-1][0], d0), (sets[-1][2], d1))):
+            kp[2 * p + i, : len(k), :2] = torch.from_numpy(k); ds[2 * p + i, : len(k)] = torch.from_numpy(d).half(); n[2 * p + i] = len(k)
+    m0, ms0 = big.match_batch_device(kp.cuda(), n.cuda(), ds.cuda())
+    torch.cuda.synchronize()
+    m0, ms0 = m0.cpu().numpy(), ms0.cpu().numpy()
+    worst_agree, worst_ds, flips, rows = 1.0, 0.0, 0, 0
+    for p in (0, 1, 4, 7, 8, 31, 32, 63):
+        a = lg.match(*sets[p])
+        n0 = len(sets[p][0])
+        worst_agree = min(worst_agree, float((m0[p, :n0] == a.matches0).mean()))
+        # mscores0 is exp(max) for mutual rows and 0 otherwise: a near-tie whose mutual flag flips between the two fp16 paths
+        # moves the score by its full value - count those rows, compare the scores where the flag agrees
+        same = (ms0[p, :n0] > 0) == (a.mscores0 > 0)
+        flips += int((~same).sum()); rows += n0
+        worst_ds = max(worst_ds, float(np.abs(ms0[p, :n0] - a.mscores0)[same].max()))
+        assert (m0[p, n0:] == -1).all() and (ms0[p, n0:] == 0).all()
+    assert flips <= 0.005 * rows, (flips, rows)
+    # and one full-size pair of the batch straight against the oracle, layer by layer through the batch handle
+    p = 5
+    m_ref, s_ref, it = _oracle(weights_dir, *sets[p])
+    x0 = big.debug_read(big.DEBUG_X, 2 * p, 600, 256)
+    rel = np.linalg.norm(x0 - it["x0_layers"][8][0].double().numpy()) / np.linalg.norm(it["x0_layers"][8][0].double().numpy())
+    agree = float((m0[p] == m_ref).mean())
+    dso = float(np.abs(ms0[p] - s_ref).max())
+    print(f"batch vs single: agreement {worst_agree:.4f} max|d| {worst_ds:.3e}; batch pair vs oracle: x rel {rel:.2e} agreement {agree:.4f} max|d| {dso:.3e}")
+    parity_report["lg_batch64_vs_single"] = {"agreement_worst": worst_agree, "mscores_maxd": worst_ds, "x_rel_vs_oracle": float(rel),
+                                             "agreement_vs_oracle": agree, "mscores_maxd_vs_oracle": dso}
+    # two fp16 paths with different LayerNorm-statistics summation order: each is within 2e-2 of the oracle, so their mutual
+    # distance is bounded by the sum
+    assert worst_agree >= 0.99 and worst_ds <= 3e-2
+    assert rel <= X_REL_BAR and agree >= 0.99 and dso <= 2e-2
+    big.close()

@@ -413,3 +413,30 @@ def test_raw_checkpoint_key_layout_round_trip():
     assert set(back) == set(sd)
     assert all(torch.equal(back[k], sd[k]) for k in sd)
     assert normalize_lightglue_keys({"self_attn.12.ffn.0.weight": 1}) == {"transformers.12.self_attn.ffn.0.weight": 1}
+
+
+def test_kernel_gelu_constants_against_erf():
+    """The HIP kernels evaluate GELU as y * sigmoid(y Q(y^2)) (lg_kernels.hip, gelu2): parse the constants from the kernel
+    source, evaluate the same formula in fp32 and compare with the exact erf form over the whole useful range."""
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "superslam_amd", "csrc", "lg_kernels.hip")).read()
+    q = [np.float32(re.search(rf"kGeluQ{i} = (-?[0-9.]+e[+-][0-9]+)f", src).group(1)) for i in range(5)]
+    y = np.linspace(-12, 12, 200001).astype(np.float32)
+    s = y * y
+    p = ((((s * q[4] + q[3]) * s + q[2]) * s + q[1]) * s + q[0])
+    with np.errstate(over="ignore"):
+        out = y * (np.float32(1) / (np.float32(1) + np.exp2(y * p)))
+    exact = torch.nn.functional.gelu(torch.from_numpy(y).double()).numpy()
+    err = np.abs(out.astype(np.float64) - exact)
+    print(f"kernel GELU vs erf: max abs {err.max():.2e}, max rel (|gelu| >= 0.05) {(err / np.maximum(np.abs(exact), 5e-2)).max():.2e}")
+    assert err.max() <= 1.0e-5
+    assert (err / np.maximum(np.abs(exact), 5e-2)).max() <= 6e-5       # < 1/4 of half an fp16 ulp (2.4e-4)
+    assert np.isfinite(out).all() and out[0] <= 0 and abs(out[-1] - 12.0) < 1e-6
+    # far tails: saturates to y / -0, never NaN
+    big = np.array([-1e4, -100.0, 100.0, 1e4], np.float32)
+    sb = big * big
+    pb = ((((sb * q[4] + q[3]) * sb + q[2]) * sb + q[1]) * sb + q[0])
+    with np.errstate(over="ignore", invalid="ignore"):
+        ob = big * (np.float32(1) / (np.float32(1) + np.exp2(big * pb)))
+    assert np.isfinite(ob).all() and ob[0] == 0 and ob[1] == 0 and ob[2] == 100.0 and ob[3] == 1e4
