@@ -84,7 +84,7 @@ hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int os
 // ---- lg_kernels.hip ----
 struct LgDims {
   int S;    // sequences (2 * pairs)
-  int NP;   // padded tokens per sequence (multiple of 128)
+  int NP;   // padded tokens per sequence (multiple of 32)
 };
 void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int* lens, int max_kp, int* lens_clamped,
                     const _Float16* desc, size_t desc_seq_stride, const float* wr, float img_w, float img_h, LgDims d,

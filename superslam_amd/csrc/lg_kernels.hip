@@ -1,6 +1,6 @@
 // LightGlue kernels (SURVEY.md 8(a)-LG restates the upstream algorithm; call sites src/LightGlue.cc:313,446).
 // Token streams are channels-last fp16 [S*NP][256]; S = 2*pairs sequences (2p = set 0, 2p+1 = set 1 of pair p),
-// NP = padded tokens per sequence.  Per-sequence valid lengths live in device memory (`lens`) so the whole
+// NP = padded tokens per sequence (a multiple of 32: 600 keypoints -> 608 tokens).  Per-sequence valid lengths live in device memory (`lens`) so the whole
 // matcher runs without a host round trip after SuperPoint's on-device top-k.
 #include <cstdlib>
 #include <type_traits>
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)(active ? qt0 + t : 0) * 4 + ks) * 512 + lane * 8);
+      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)(active ? min(qt0 + t, nt32 - 1) : 0) * 4 + ks) * 512 + lane * 8);  // NP is a multiple of 32, not of 32 QT
   float m[QT], l[QT];
   f16x_t o[QT][2];
 #pragma unroll
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(256) void k_lg_sim(const _Float16* __restrict__ md,
   }
 }
 void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s) {
-  hipLaunchKernelGGL(k_lg_sim, dim3(d.NP / 128, d.NP / 32, d.S / 2), dim3(256), 0, s, md, lens, d.NP, sim);
+  hipLaunchKernelGGL(k_lg_sim, dim3((d.NP + 127) / 128, d.NP / 32, d.S / 2), dim3(256), 0, s, md, lens, d.NP, sim);
 }
 
 // workspace per pair (floats): [0,NP) lse_row, [NP,2NP) lse_col, [2NP,3NP) max0, [3NP,4NP) m0 (int), [4NP,5NP) m1 (int)
@@ -1457,9 +1457,9 @@ void launch_lg_assign(const float* sim, const float* logsig, const int* lens, Lg
                       int32_t* matches0, float* mscores0, float thr, hipStream_t s) {
   const int P = d.S / 2;
   hipLaunchKernelGGL(k_assign_row_lse, dim3(d.NP / 4, P), dim3(256), 0, s, sim, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_col_lse, dim3(d.NP / 64, P), dim3(64 * kColRG), 0, s, sim, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_col_lse, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, lens, d.NP, ws);
   hipLaunchKernelGGL(k_assign_row_arg, dim3(d.NP / 4, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_col_arg, dim3(d.NP / 64, P), dim3(64 * kColRG), 0, s, sim, logsig, lens, d.NP, ws);
+  hipLaunchKernelGGL(k_assign_col_arg, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, logsig, lens, d.NP, ws);
   hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr,
                      matches0, mscores0);
 }
