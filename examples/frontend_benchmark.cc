@@ -1,20 +1,26 @@
 // Per-frame benchmark of the HIP front-end on a stereo sequence - the counterpart of the reference's
-// examples/stereo/benchmark.cc:46-108 for the part of SuperSLAM this library replaces.
-// Per frame it runs exactly StereoFrontEnd's unit of work (src/StereoFrontEnd.cc:10-48): extract_stereo, the device
-// LightGlue match, the consumer's disparity gate (uL - uR >= 1, |vL - vR| <= 2) - and, with --keyframe-match, the
-// second LightGlue call of the tracker against the previous frame's left features (src/VoEstimator.cc:243-246).
-// Output mirrors the reference benchmark: frames, per-frame ms mean / p50 / p95 / max, fps over wall time, the
-// real-time (>= 10 fps) verdict.  Timing brackets the front-end call only; image decode runs ahead on a second thread
-// into a small ring, as the reference times `track_stereo` after `cv::imread`.
+// examples/stereo/benchmark.cc:46-108 / examples/stereo/kitti.cc:70-129 for the part of SuperSLAM this library replaces
+// (SURVEY 8(f) rows 1 and 3).  Per frame it runs exactly StereoFrontEnd's unit of work (src/StereoFrontEnd.cc:10-48):
+// extract_stereo, the device LightGlue match, the consumer's disparity gate (uL - uR >= 1, |vL - vR| <= 2) - and, with
+// --keyframe-match, the second LightGlue call of the tracker against the previous frame's left features
+// (src/VoEstimator.cc:243-246).  Output mirrors the reference benchmark: frames, per-frame ms mean / p50 / p95 / max, fps over
+// wall time, the real-time (>= 10 fps) verdict; timing brackets the front-end call only, as the reference times
+// `track_stereo` after `cv::imread`.
 //
-// Input: a KITTI-style directory  <sequence>/image_0/000000.pgm, <sequence>/image_1/000000.pgm ...  (binary PGM, "P5";
-// this image ships neither OpenCV nor libpng - `mogrify -format pgm *.png` converts a KITTI sequence once), or
-// --synthetic N: N procedurally generated 1376x376 pairs (value noise + rectangles, right = left shifted by 16..48 px).
+// Input, as the reference's runners read it: <sequence>/times.txt (one timestamp per line; optional here - without it frames
+// are read until one is missing), <sequence>/image_0/%06d.png and image_1/%06d.png (8/16-bit gray or RGB PNG, decoded by
+// include/superslam_hip/image_io.hpp; .pgm is the fallback extension), or --synthetic N procedurally generated 1376x376 pairs.
+//
+// Decode runs AHEAD on a second thread, straight into the extractor's pinned upload ring (sship_sp_ring_*): the decoder
+// writes pixels into pinned host memory and starts the H2D copy of frame i + 1..i + 3 on the ring's copy stream while the
+// tracking thread is still computing frame i; --no-ring uses the copying host API (the reference's in-line staging) instead.
+// What this runner does NOT link is the reference's GPU-free core (VoEstimator / WindowSmoother need GTSAM, absent here):
+// it produces the StereoFrame inputs, not poses.
 //
 // build:  g++ -std=c++17 -O2 -Iinclude examples/frontend_benchmark.cc -o frontend_benchmark
-//             -Lsuperslam_amd/lib -lsuperslam_hip -Wl,-rpath,$PWD/superslam_amd/lib -Wl,-rpath,/opt/rocm/lib -lpthread
+//             -Lsuperslam_amd/lib -lsuperslam_hip -Wl,-rpath,$PWD/superslam_amd/lib -Wl,-rpath,/opt/rocm/lib -lpthread -lz
 // run:    ./frontend_benchmark --sp sp.safetensors --lg lg.safetensors (--sequence DIR | --synthetic 200) [--keyframe-match]
-//                              [--max-kp 600] [--threshold 0.005] [--border 4]
+//                              [--max-kp 600] [--threshold 0.005] [--border 4] [--no-ring]
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -22,7 +28,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
-#include <fstream>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -30,40 +35,14 @@
 #include <vector>
 
 #include "superslam_hip/frontend.hpp"
+#include "superslam_hip/image_io.hpp"
 
 namespace sh = superslam_hip;
 
 namespace {
 
-struct Frame {
-  std::vector<uint8_t> left, right;
-  int rows = 0, cols = 0;
-  bool ok = false;
-};
-
-bool read_pgm(const std::string& path, std::vector<uint8_t>& px, int& rows, int& cols) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) return false;
-  std::string magic;
-  f >> magic;
-  if (magic != "P5") return false;
-  int vals[3], got = 0;
-  while (got < 3 && f) {  // width, height, maxval with '#' comments in between
-    f >> std::ws;
-    if (f.peek() == '#') { std::string skip; std::getline(f, skip); continue; }
-    f >> vals[got++];
-  }
-  if (got < 3 || vals[2] != 255) return false;
-  f.get();  // the single whitespace byte after maxval
-  cols = vals[0]; rows = vals[1];
-  px.resize((size_t)rows * cols);
-  f.read(reinterpret_cast<char*>(px.data()), (std::streamsize)px.size());
-  return (size_t)f.gcount() == px.size();
-}
-
 // deterministic texture: two octaves of value noise plus filled rectangles (corners for the detector)
-void synth_pair(int idx, int rows, int cols, Frame& fr) {
-  fr.rows = rows; fr.cols = cols; fr.left.assign((size_t)rows * cols, 0); fr.right.assign((size_t)rows * cols, 0);
+void synth_pair(int idx, int rows, int cols, uint8_t* left, uint8_t* right) {
   uint32_t s = 0x9E3779B9u * (uint32_t)(idx + 1);
   auto rnd = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
   const int gw = cols / 16 + 2, gh = rows / 16 + 2;
@@ -76,18 +55,17 @@ void synth_pair(int idx, int rows, int cols, Frame& fr) {
       const float ax = fx - x0, ay = fy - y0;
       const float v = (grid[y0 * gw + x0] * (1 - ax) + grid[y0 * gw + x0 + 1] * ax) * (1 - ay) +
                       (grid[(y0 + 1) * gw + x0] * (1 - ax) + grid[(y0 + 1) * gw + x0 + 1] * ax) * ay;
-      fr.left[(size_t)y * cols + x] = (uint8_t)(40.f + 120.f * v);
+      left[(size_t)y * cols + x] = (uint8_t)(40.f + 120.f * v);
     }
   for (int r = 0; r < 160; ++r) {
     const int w = 8 + (int)(rnd() % 40), h = 8 + (int)(rnd() % 40);
     const int x0 = (int)(rnd() % (uint32_t)(cols - w)), y0 = (int)(rnd() % (uint32_t)(rows - h));
     const uint8_t c = (uint8_t)(rnd() % 256);
-    for (int y = y0; y < y0 + h; ++y) std::memset(&fr.left[(size_t)y * cols + x0], c, (size_t)w);
+    for (int y = y0; y < y0 + h; ++y) std::memset(&left[(size_t)y * cols + x0], c, (size_t)w);
   }
   const int d = 16 + (int)(rnd() % 3) * 16;  // SuperPoint on synthetic weights is shift-equivariant in 8-px steps
   for (int y = 0; y < rows; ++y)
-    for (int x = 0; x < cols; ++x) fr.right[(size_t)y * cols + x] = fr.left[(size_t)y * cols + std::min(cols - 1, x + d)];
-  fr.ok = true;
+    for (int x = 0; x < cols; ++x) right[(size_t)y * cols + x] = left[(size_t)y * cols + std::min(cols - 1, x + d)];
 }
 
 float percentile(std::vector<float> v, double p) {  // same definition as the reference benchmark
@@ -96,91 +74,123 @@ float percentile(std::vector<float> v, double p) {  // same definition as the re
   return v[std::min(v.size() - 1, (size_t)(p * (v.size() - 1)))];
 }
 
+struct Source {
+  std::string sequence, ext = "png";
+  int synthetic = 0;
+  size_t count = 0;  // frames announced by times.txt (0: until a file is missing)
+  // frame ni into caller-provided memory of rows * cols bytes each; false at the end of the sequence
+  bool load(int ni, int rows, int cols, uint8_t* left, uint8_t* right) const {
+    if (synthetic > 0) {
+      if (ni >= synthetic) return false;
+      synth_pair(ni, rows, cols, left, right);
+      return true;
+    }
+    if (count && (size_t)ni >= count) return false;
+    char name[32];
+    std::snprintf(name, sizeof name, "%06d.%s", ni, ext.c_str());
+    int r = 0, c = 0;
+    auto into = [&](uint8_t* dst) { return [=](int rr, int cc) -> uint8_t* { return (rr == rows && cc == cols) ? dst : nullptr; }; };
+    return sh::read_gray_image(sequence + "/image_0/" + name, r, c, into(left)) &&
+           sh::read_gray_image(sequence + "/image_1/" + name, r, c, into(right));
+  }
+};
+
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string sp_path, lg_path, sequence;
-  int synthetic = 0, max_kp = 600, border = 4;
+  std::string sp_path, lg_path;
+  Source src;
+  int max_kp = 600, border = 4;
   double thr = 0.005;
-  bool keyframe = false;
+  bool keyframe = false, use_ring = true;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
     if (a == "--sp") sp_path = next();
     else if (a == "--lg") lg_path = next();
-    else if (a == "--sequence") sequence = next();
-    else if (a == "--synthetic") synthetic = std::atoi(next());
+    else if (a == "--sequence") src.sequence = next();
+    else if (a == "--synthetic") src.synthetic = std::atoi(next());
     else if (a == "--max-kp") max_kp = std::atoi(next());
     else if (a == "--threshold") thr = std::atof(next());
     else if (a == "--border") border = std::atoi(next());
     else if (a == "--keyframe-match") keyframe = true;
+    else if (a == "--no-ring") use_ring = false;
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
-  if (sp_path.empty() || lg_path.empty() || (sequence.empty() && synthetic <= 0)) {
+  if (sp_path.empty() || lg_path.empty() || (src.sequence.empty() && src.synthetic <= 0)) {
     std::fprintf(stderr, "usage: %s --sp W.safetensors --lg W.safetensors (--sequence DIR | --synthetic N) [--keyframe-match] "
-                         "[--max-kp 600] [--threshold 0.005] [--border 4]\n", argv[0]);
+                         "[--max-kp 600] [--threshold 0.005] [--border 4] [--no-ring]\n", argv[0]);
     return 2;
   }
 
-  // ---- decode-ahead producer: a ring of at most 4 decoded pairs ----
-  std::deque<Frame> ring;
+  // ---- frame geometry from the first frame; timestamps as the reference reads them ----
+  int rows = 376, cols = 1376;
+  std::vector<double> ts;
+  if (src.synthetic <= 0) {
+    ts = sh::read_times(src.sequence + "/times.txt");
+    src.count = ts.size();
+    std::vector<uint8_t> probe;
+    if (!sh::read_gray_image(src.sequence + "/image_0/000000.png", probe, rows, cols)) {
+      src.ext = "pgm";
+      if (!sh::read_gray_image(src.sequence + "/image_0/000000.pgm", probe, rows, cols)) {
+        std::fprintf(stderr, "Not a KITTI sequence dir (need image_0/000000.png or .pgm): %s\n", src.sequence.c_str());
+        return 1;
+      }
+    }
+  }
+  sh::SuperPoint extractor(sp_path, max_kp, thr, border);
+  sh::LightGlue matcher(lg_path, cols, rows, max_kp);
+  if (!extractor.initialize() || !matcher.initialize()) {
+    std::fprintf(stderr, "initialisation failed: %s\n", sship_last_error());
+    return 1;
+  }
+  constexpr int kDepth = 4;
+  if (use_ring && !extractor.ring_create(kDepth, rows, cols, 1)) {
+    std::fprintf(stderr, "upload ring: %s\n", extractor.last_error().c_str());
+    return 1;
+  }
+
+  // ---- decode-ahead producer: frame ni -> ring slot ni % kDepth (pinned memory) -> asynchronous upload ----
+  std::vector<std::vector<uint8_t>> plain(use_ring ? 0 : 2 * kDepth, std::vector<uint8_t>((size_t)rows * cols));
   std::mutex mu;
-  std::condition_variable cv_not_full, cv_not_empty;
+  std::condition_variable cv_free, cv_ready;
+  int produced = 0, consumed = 0;  // frames decoded / frames whose slot has been handed back
   bool done = false;
   std::thread producer([&]() {
     for (int ni = 0;; ++ni) {
-      Frame fr;
-      if (synthetic > 0) {
-        if (ni >= synthetic) break;
-        synth_pair(ni, 376, 1376, fr);
-      } else {
-        char name[32];
-        std::snprintf(name, sizeof name, "%06d.pgm", ni);
-        int r2 = 0, c2 = 0;
-        if (!read_pgm(sequence + "/image_0/" + name, fr.left, fr.rows, fr.cols) ||
-            !read_pgm(sequence + "/image_1/" + name, fr.right, r2, c2) || r2 != fr.rows || c2 != fr.cols)
-          break;  // end of the sequence (or an unreadable / mismatched pair)
-        fr.ok = true;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_free.wait(lk, [&] { return ni - consumed < kDepth; });  // the slot's previous frame has been extracted
       }
-      std::unique_lock<std::mutex> lk(mu);
-      cv_not_full.wait(lk, [&] { return ring.size() < 4; });
-      ring.push_back(std::move(fr));
-      cv_not_empty.notify_one();
+      const int slot = ni % kDepth;
+      uint8_t* l = use_ring ? extractor.ring_host(slot, 0) : plain[2 * slot].data();
+      uint8_t* r = use_ring ? extractor.ring_host(slot, 1) : plain[2 * slot + 1].data();
+      if (!src.load(ni, rows, cols, l, r)) break;
+      if (use_ring) extractor.ring_upload(slot);
+      std::lock_guard<std::mutex> lk(mu);
+      produced = ni + 1;
+      cv_ready.notify_one();
     }
     std::lock_guard<std::mutex> lk(mu);
     done = true;
-    cv_not_empty.notify_one();
+    cv_ready.notify_one();
   });
-  auto pop = [&](Frame& fr) {
-    std::unique_lock<std::mutex> lk(mu);
-    cv_not_empty.wait(lk, [&] { return !ring.empty() || done; });
-    if (ring.empty()) return false;
-    fr = std::move(ring.front());
-    ring.pop_front();
-    cv_not_full.notify_one();
-    return true;
-  };
-
-  Frame fr;
-  if (!pop(fr)) { std::fprintf(stderr, "no frames\n"); producer.join(); return 1; }
-  sh::SuperPoint extractor(sp_path, max_kp, thr, border);
-  sh::LightGlue matcher(lg_path, fr.cols, fr.rows, max_kp);
-  if (!extractor.initialize() || !matcher.initialize()) {
-    std::fprintf(stderr, "initialisation failed: %s\n", sship_last_error());
-    { std::lock_guard<std::mutex> lk(mu); done = true; ring.clear(); }
-    cv_not_full.notify_all();
-    producer.detach();
-    return 1;
-  }
 
   std::vector<float> ms;
   long stereo_points = 0, stereo_matches = 0, track_matches = 0;
   sh::Features prev_left;
   const auto wall0 = std::chrono::steady_clock::now();
-  do {
-    const sh::Image l{fr.left.data(), fr.rows, fr.cols, 1, 0}, r{fr.right.data(), fr.rows, fr.cols, 1, 0};
+  for (int ni = 0;; ++ni) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_ready.wait(lk, [&] { return produced > ni || done; });
+      if (produced <= ni) break;
+    }
+    const int slot = ni % kDepth;
     const auto t1 = std::chrono::steady_clock::now();
-    auto feats = extractor.extract_stereo(l, r);
+    std::pair<sh::Features, sh::Features> feats;
+    if (use_ring) feats = extractor.extract_stereo_ring(slot);
+    else feats = extractor.extract_stereo(sh::Image{plain[2 * slot].data(), rows, cols, 1, 0}, sh::Image{plain[2 * slot + 1].data(), rows, cols, 1, 0});
     sh::MatchResult lr = matcher.match(feats.first.keypoints, feats.first.descriptors, feats.second.keypoints, feats.second.descriptors);
     for (const sh::DMatch& m : lr.matches) {  // StereoFrontEnd's gate
       const sh::KeyPoint &kl = feats.first.keypoints[m.queryIdx], &kr = feats.second.keypoints[m.trainIdx];
@@ -192,18 +202,28 @@ int main(int argc, char** argv) {
     const auto t2 = std::chrono::steady_clock::now();
     ms.push_back((float)std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count() / 1000.0f);
     if (keyframe) prev_left = std::move(feats.first);  // holds its pool slot until the next frame replaces it
-  } while (pop(fr));
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      consumed = ni + 1;  // the extract call that read this slot has returned: the decoder may overwrite it
+      cv_free.notify_one();
+    }
+  }
   const double wall = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count() / 1000.0;
   producer.join();
+  if (ms.empty()) { std::fprintf(stderr, "no frames\n"); return 1; }
 
-  const double mean = ms.empty() ? 0.0 : std::accumulate(ms.begin(), ms.end(), 0.0) / ms.size();
+  const double mean = std::accumulate(ms.begin(), ms.end(), 0.0) / ms.size();
   std::printf("=========== SuperSLAM HIP front-end benchmark ===========\n");
+  std::printf("source           : %s, %dx%d, %s%s\n", src.synthetic > 0 ? "synthetic" : (src.ext == "png" ? "PNG sequence" : "PGM sequence"), cols, rows,
+              use_ring ? "pinned upload ring" : "copying host API", ts.empty() ? "" : ", times.txt");
   std::printf("frames           : %zu\n", ms.size());
   std::printf("per-frame ms      mean=%.2f p50=%.2f p95=%.2f max=%.2f\n", mean, percentile(ms, 0.50), percentile(ms, 0.95), percentile(ms, 1.0));
   std::printf("throughput        : %.2f fps over %.1fs wall\n", wall > 0 ? ms.size() / wall : 0.0, wall);
   std::printf("real-time (>=10fps): %s\n", mean > 0 && (1000.0 / mean) >= 10.0 ? "YES" : "NO");
-  std::printf("stereo matches    : %.1f per frame, %.1f pass the disparity gate\n", ms.empty() ? 0.0 : (double)stereo_matches / ms.size(),
-              ms.empty() ? 0.0 : (double)stereo_points / ms.size());
+  if (!ts.empty() && ts.size() >= ms.size() && ms.size() > 1)
+    std::printf("sequence rate     : %.2f fps (times.txt), processed at %.1fx real time\n", (ms.size() - 1) / (ts[ms.size() - 1] - ts[0]),
+                (ts[ms.size() - 1] - ts[0]) / std::max(1e-9, wall));
+  std::printf("stereo matches    : %.1f per frame, %.1f pass the disparity gate\n", (double)stereo_matches / ms.size(), (double)stereo_points / ms.size());
   if (keyframe) std::printf("keyframe matches  : %.1f per frame\n", ms.size() > 1 ? (double)track_matches / (ms.size() - 1) : 0.0);
   std::printf("=========================================================\n");
   return 0;

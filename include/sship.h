@@ -140,6 +140,17 @@ int sship_sp_extract(sship_sp* sp, const uint8_t* img, int h, int w, int stride,
  * pass; the pair must share resolution (:762-765). */
 int sship_sp_extract_stereo(sship_sp* sp, const uint8_t* left, const uint8_t* right, int h, int w,
                             int stride, int channels, sship_features* out_left, sship_features* out_right);
+/* Decode-ahead upload ring for dataset runners.  No reference counterpart: the reference stages every frame
+ * in-line (clone + convertTo + memcpy into one pinned buffer + H2D, src/SuperPoint.cc:768-795); here `depth` stereo frames live in
+ * pinned host memory, so a decoder thread writes pixels straight into a slot (sship_sp_ring_host), starts its H2D on the ring's
+ * own copy stream (sship_sp_ring_upload - the one call that may run on another thread than the handle's owner), and the
+ * tracking thread extracts from the uploaded slot (sship_sp_extract_stereo_ring = sship_sp_extract_stereo without the host
+ * copy and with the upload already overlapped with the previous frame's compute).  Images are [h][w*channels] u8, 1 or 3 (BGR)
+ * channels; the caller keeps slot reuse behind the extract call that consumes it. */
+int sship_sp_ring_create(sship_sp* sp, int depth, int h, int w, int channels);
+uint8_t* sship_sp_ring_host(sship_sp* sp, int slot, int image /* 0 left, 1 right */);
+int sship_sp_ring_upload(sship_sp* sp, int slot);
+int sship_sp_extract_stereo_ring(sship_sp* sp, int slot, sship_features* out_left, sship_features* out_right);
 /* SuperPoint::infer host path (src/SuperPoint.cc:322-348,427-528): keypoints + CV_32F [n,256] descriptors
  * on the host.  kp_xys [3*max_kp], desc_f32 [max_kp*256]. */
 int sship_sp_infer_host(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels,

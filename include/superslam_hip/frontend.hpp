@@ -215,6 +215,26 @@ public:
     r.descriptors = pool_->wrap(orr.slot, orr.n);
     return {std::move(l), std::move(r)};
   }
+  // Decode-ahead upload ring (sship_sp_ring_*, include/sship.h): a decoder thread fills ring_host(slot, 0 / 1) and calls
+  // ring_upload(slot); the tracking thread then calls extract_stereo_ring(slot).
+  bool ring_create(int depth, int rows, int cols, int channels) {
+    if (!sp_ || sship_sp_ring_create(sp_, depth, rows, cols, channels) != SSHIP_OK) { last_error_ = sship_last_error(); return false; }
+    return true;
+  }
+  uint8_t* ring_host(int slot, int image) { return sp_ ? sship_sp_ring_host(sp_, slot, image) : nullptr; }
+  bool ring_upload(int slot) { return sp_ && sship_sp_ring_upload(sp_, slot) == SSHIP_OK; }
+  std::pair<Features, Features> extract_stereo_ring(int slot) {
+    Features l, r;
+    if (!sp_) return {l, r};
+    std::vector<float> kl(3 * static_cast<size_t>(max_keypoints_)), kr(kl.size());
+    sship_features ol{kl.data(), 0, nullptr, -1}, orr{kr.data(), 0, nullptr, -1};
+    if (sship_sp_extract_stereo_ring(sp_, slot, &ol, &orr) != SSHIP_OK) last_error_ = sship_last_error();
+    fill(l.keypoints, kl.data(), ol.n);
+    fill(r.keypoints, kr.data(), orr.n);
+    l.descriptors = pool_->wrap(ol.slot, ol.n);
+    r.descriptors = pool_->wrap(orr.slot, orr.n);
+    return {std::move(l), std::move(r)};
+  }
   const std::string& last_error() const { return last_error_; }
   int pool_in_use() const { return pool_ ? pool_->in_use() : 0; }
   sship_sp* handle() const { return sp_; }

@@ -530,8 +530,17 @@ struct sship_sp {
   PinBuf h_kp, h_n, h_img;
   int cap = 0;
   float thr_f = 0.f;
+  // decode-ahead upload ring (sship_sp_ring_*): `depth` stereo frames in pinned host memory + their device copies
+  struct Ring {
+    int depth = 0, h = 0, w = 0, ch = 0;
+    size_t img_bytes = 0;
+    std::vector<void*> host, dev;     // [depth]: left image then right image, contiguous
+    std::vector<hipEvent_t> uploaded;  // [depth]
+    hipStream_t copy_stream = nullptr;
+  } ring;
 };
 
+static void ring_free(sship_sp* sp);
 static void sp_shapes(int H, int W, int& H2, int& W2, int& H4, int& W4, int& Hc, int& Wc) {
   H2 = H / 2; W2 = W / 2; H4 = H2 / 2; W4 = W2 / 2; Hc = H4 / 2; Wc = W4 / 2;  // MaxPool2d(2,2) floors
 }
@@ -730,6 +739,7 @@ extern "C" void sship_sp_destroy(sship_sp* sp) {
   if (sp->w1a_frag) (void)hipFree(sp->w1a_frag);
   if (sp->w1a_fragb) (void)hipFree(sp->w1a_fragb);
   if (sp->pool) sship_pool_destroy(sp->pool);
+  ring_free(sp);
   if (sp->stream) (void)hipStreamDestroy(sp->stream);
   delete sp;
 }
@@ -864,6 +874,7 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
 }
 
 // host-image front: upload (pinned) -> gray -> batch path into pool slots -> D2H keypoints.
+static int sp_extract_device(sship_sp* sp, const uint8_t* gray, int B, int h, int w, sship_features* const* outs);
 static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int h, int w, int stride, int channels,
                            sship_features* const* outs) {
   if (channels != 1 && channels != 3) return fail(SSHIP_ERR_INVALID, "image must have 1 or 3 channels");
@@ -874,13 +885,17 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
   uint8_t* hp = sp->h_img.as<uint8_t>();
   for (int b = 0; b < B; ++b)
     for (int y = 0; y < h; ++y) memcpy(hp + b * img_bytes + y * row, imgs[b] + (size_t)y * stride, row);
-  const uint8_t* gray = sp->img.as<uint8_t>();
   if (channels == 1) {
     SSHIP_HIP_CHECK(hipMemcpyAsync(sp->img.p, hp, img_bytes * B, hipMemcpyHostToDevice, s));
   } else {
     SSHIP_HIP_CHECK(hipMemcpyAsync(sp->gray_in.p, hp, img_bytes * B, hipMemcpyHostToDevice, s));
     launch_bgr2gray(sp->gray_in.as<uint8_t>(), B * h * w, sp->img.as<uint8_t>(), s);
   }
+  return sp_extract_device(sp, sp->img.as<uint8_t>(), B, h, w, outs);
+}
+// `gray`: B u8 images [h][w] resident on the device, ordered with sp->stream
+static int sp_extract_device(sship_sp* sp, const uint8_t* gray, int B, int h, int w, sship_features* const* outs) {
+  hipStream_t s = sp->stream;
   g_timer.begin(s);
   for (int b = 0; b < B; ++b) { outs[b]->n = 0; outs[b]->desc_dev = nullptr; outs[b]->slot = -1; }
   if (int rc = sp_network(sp, gray, B, h, w, s, false)) return rc;
@@ -935,6 +950,58 @@ extern "C" int sship_sp_extract_stereo(sship_sp* sp, const uint8_t* left, const 
   const uint8_t* imgs[2] = {left, right};
   sship_features* outs[2] = {out_left, out_right};
   return sp_extract_host(sp, imgs, 2, h, w, stride, channels, outs);
+}
+// ---- decode-ahead upload ring (include/sship.h) ----
+static void ring_free(sship_sp* sp) {
+  auto& r = sp->ring;
+  for (void* p : r.host) if (p) (void)hipHostFree(p);
+  for (void* p : r.dev) if (p) (void)hipFree(p);
+  for (hipEvent_t e : r.uploaded) if (e) (void)hipEventDestroy(e);
+  if (r.copy_stream) (void)hipStreamDestroy(r.copy_stream);
+  r = sship_sp::Ring();
+}
+extern "C" int sship_sp_ring_create(sship_sp* sp, int depth, int h, int w, int channels) {
+  bind_thread();
+  if (!sp || depth < 1 || depth > 16 || h <= 0 || w <= 0 || (channels != 1 && channels != 3)) return fail(SSHIP_ERR_INVALID, "sp_ring_create: bad arguments");
+  if (int rc = sp_ensure(sp, 2, h, w)) return rc;
+  ring_free(sp);
+  auto& r = sp->ring;
+  r.depth = depth; r.h = h; r.w = w; r.ch = channels; r.img_bytes = (size_t)h * w * channels;
+  r.host.assign(depth, nullptr); r.dev.assign(depth, nullptr); r.uploaded.assign(depth, nullptr);
+  auto bail = [&](const char* what, hipError_t e) { ring_free(sp); return fail(SSHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+  if (hipError_t e = hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking)) return bail("sp_ring_create: stream", e);
+  for (int i = 0; i < depth; ++i) {
+    if (hipError_t e = hipHostMalloc(&r.host[i], 2 * r.img_bytes, hipHostMallocDefault)) return bail("sp_ring_create: pinned host frame", e);
+    if (hipError_t e = hipMalloc(&r.dev[i], 2 * r.img_bytes)) return bail("sp_ring_create: device frame", e);
+    if (hipError_t e = hipEventCreateWithFlags(&r.uploaded[i], hipEventDisableTiming)) return bail("sp_ring_create: event", e);
+  }
+  return SSHIP_OK;
+}
+extern "C" uint8_t* sship_sp_ring_host(sship_sp* sp, int slot, int image) {
+  if (!sp || slot < 0 || slot >= sp->ring.depth || image < 0 || image > 1) return nullptr;
+  return static_cast<uint8_t*>(sp->ring.host[slot]) + (size_t)image * sp->ring.img_bytes;
+}
+extern "C" int sship_sp_ring_upload(sship_sp* sp, int slot) {
+  bind_thread();
+  if (!sp || slot < 0 || slot >= sp->ring.depth) return fail(SSHIP_ERR_INVALID, "sp_ring_upload: bad slot");
+  auto& r = sp->ring;
+  SSHIP_HIP_CHECK(hipMemcpyAsync(r.dev[slot], r.host[slot], 2 * r.img_bytes, hipMemcpyHostToDevice, r.copy_stream));
+  SSHIP_HIP_CHECK(hipEventRecord(r.uploaded[slot], r.copy_stream));
+  return SSHIP_OK;
+}
+extern "C" int sship_sp_extract_stereo_ring(sship_sp* sp, int slot, sship_features* out_left, sship_features* out_right) {
+  bind_thread();
+  if (!sp || !out_left || !out_right || slot < 0 || slot >= sp->ring.depth) return fail(SSHIP_ERR_INVALID, "sp_extract_stereo_ring: bad arguments");
+  auto& r = sp->ring;
+  if (int rc = sp_ensure(sp, 2, r.h, r.w)) return rc;
+  SSHIP_HIP_CHECK(hipStreamWaitEvent(sp->stream, r.uploaded[slot], 0));
+  const uint8_t* gray = static_cast<const uint8_t*>(r.dev[slot]);
+  if (r.ch == 3) {
+    launch_bgr2gray(static_cast<const uint8_t*>(r.dev[slot]), 2 * r.h * r.w, sp->img.as<uint8_t>(), sp->stream);
+    gray = sp->img.as<uint8_t>();
+  }
+  sship_features* outs[2] = {out_left, out_right};
+  return sp_extract_device(sp, gray, 2, r.h, r.w, outs);
 }
 extern "C" int sship_desc_to_host(const void* desc_dev, int count, int dim, float* out) {
   bind_thread();

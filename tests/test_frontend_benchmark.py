@@ -16,9 +16,10 @@ def _build():
     libdir = os.path.join(ROOT, "superslam_amd", "lib")
     src = os.path.join(ROOT, "examples", "frontend_benchmark.cc")
     hdr = os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp")
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdr2 = os.path.join(ROOT, "include", "superslam_hip", "image_io.hpp")
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
-                               "-L" + libdir, "-lsuperslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+                               "-L" + libdir, "-lsuperslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-lz"])
     return BIN
 
 
@@ -65,3 +66,118 @@ def test_benchmark_runner_reads_a_pgm_sequence(weights_dir, tmp_path):
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert _field(out.stdout, "frames") == 3
+
+
+def write_png(path, img, filter_type=None, color=False, sixteen=False):
+    """Minimal PNG writer (zlib + the five row filters) for the decoder tests: img u8 [H,W] (gray) or [H,W,3] (RGB)."""
+    import struct
+    import zlib
+
+    a = np.ascontiguousarray(img)
+    if sixteen:
+        a = np.stack([a, np.zeros_like(a)], -1)          # big-endian 16-bit samples: high byte = the 8-bit value
+    h, w = a.shape[:2]
+    row = a.reshape(h, -1).astype(np.int32)
+    bpp = row.shape[1] // w
+    raw = bytearray()
+    prev = np.zeros(row.shape[1], np.int32)
+    for y in range(h):
+        ft = (y % 5) if filter_type is None else filter_type
+        cur = row[y]
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if ft == 0:
+            out = cur
+        elif ft == 1:
+            out = cur - left
+        elif ft == 2:
+            out = cur - prev
+        elif ft == 3:
+            out = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            out = cur - pred
+        raw.append(ft)
+        raw += (out & 0xff).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+    ihdr = struct.pack(">IIBBBBB", w, h, 16 if sixteen else 8, 2 if color else 0, 0, 0, 0)
+    comp = zlib.compress(bytes(raw), 6)
+    with open(path, "wb") as f:   # two IDAT chunks: the decoder must concatenate them
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", comp[: len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:])
+                + chunk(b"IEND", b""))
+
+
+def _build_io_test():
+    binp = os.path.join(ROOT, "superslam_amd", "lib", "test_image_io")
+    src = os.path.join(ROOT, "tests", "cpp", "test_image_io.cc")
+    hdr = os.path.join(ROOT, "include", "superslam_hip", "image_io.hpp")
+    if not os.path.exists(binp) or os.path.getmtime(binp) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", binp, "-lz"])
+    return binp
+
+
+def test_png_and_pgm_decoders_bit_exact(tmp_path):
+    """include/superslam_hip/image_io.hpp against PNGs written here with every row filter, split IDAT, gray / RGB / 16-bit."""
+    from oracle import hostpath as H
+    from superslam_amd.synth import make_frame
+
+    g = make_frame(37, 53, 5, n_rects=6)
+    rgb = np.stack([make_frame(37, 53, 6, n_rects=6), g, make_frame(37, 53, 7, n_rects=6)], -1)
+    cases = {}
+    for ft in (None, 0, 1, 2, 3, 4):
+        name = f"gray_f{ft}.png"
+        write_png(tmp_path / name, g, ft)
+        cases[name] = g
+    write_png(tmp_path / "rgb.png", rgb, None, color=True)
+    cases["rgb.png"] = H.bgr2gray_u8(rgb[..., ::-1])      # cv::imread gives BGR, track_stereo converts BGR2GRAY
+    write_png(tmp_path / "gray16.png", g, None, sixteen=True)
+    cases["gray16.png"] = g
+    with open(tmp_path / "plain.pgm", "wb") as f:
+        f.write(b"P5\n# comment\n53 37\n255\n" + g.tobytes())
+    cases["plain.pgm"] = g
+    with open(tmp_path / "times.txt", "w") as f:
+        f.write("0.000000e+00\n1.036224e-01\n2.070932e-01\n\n9.9\n")
+    for name, want in cases.items():
+        out = subprocess.run([_build_io_test(), str(tmp_path / name)], capture_output=True, timeout=60)
+        assert out.returncode == 0, (name, out.stderr)
+        hdr, _, body = out.stdout.partition(b"\n")
+        r, c = map(int, hdr.split())
+        got = np.frombuffer(body, np.uint8).reshape(r, c)
+        np.testing.assert_array_equal(got, want, err_msg=name)
+    out = subprocess.run([_build_io_test(), "--times", str(tmp_path / "times.txt")], capture_output=True, text=True, timeout=60)
+    assert out.stdout.split() == ["3", "0.000000", "0.103622", "0.207093"]     # stops at the first empty line, as the reference
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not a png")
+    assert subprocess.run([_build_io_test(), str(bad)], capture_output=True, timeout=60).returncode == 1
+
+
+@pytest.mark.gpu
+def test_benchmark_runner_reads_a_kitti_style_png_sequence_through_the_upload_ring(weights_dir, tmp_path):
+    from superslam_amd.synth import make_stereo_pair
+
+    for cam in ("image_0", "image_1"):
+        os.makedirs(tmp_path / cam)
+    with open(tmp_path / "times.txt", "w") as f:
+        for i in range(6):
+            f.write("%e\n" % (0.1 * i))
+    for i in range(7):    # one more frame on disk than times.txt announces
+        l, r = make_stereo_pair(200, 328, 100 + i)
+        write_png(tmp_path / "image_0" / f"{i:06d}.png", l)
+        write_png(tmp_path / "image_1" / f"{i:06d}.png", r)
+    res = {}
+    for mode in ([], ["--no-ring"]):
+        out = subprocess.run([_build(), "--sp", weights_dir["sp_path"], "--lg", weights_dir["lg_path"], "--sequence", str(tmp_path), *mode],
+                             capture_output=True, text=True, timeout=300)
+        print(out.stdout)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert _field(out.stdout, "frames") == 6 and "PNG sequence" in out.stdout and "times.txt" in out.stdout
+        assert ("pinned upload ring" in out.stdout) == (not mode)
+        m = re.search(r"stereo matches\s*:\s*([0-9.]+) per frame, ([0-9.]+) pass", out.stdout)
+        res[bool(mode)] = (float(m.group(1)), float(m.group(2)))
+    assert res[False] == res[True]      # the ring path and the copying path see the same pixels

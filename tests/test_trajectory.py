@@ -1,0 +1,105 @@
+"""Trajectory writers and the ATE / KITTI-segment metrics (superslam_amd/trajectory.py, include/superslam_hip/trajectory.hpp)
+against closed-form trajectories: what the KITTI-00 gate of BASELINE configs[3] would be scored with (the gate itself needs the
+dataset, real weights and the reference's GTSAM estimator - none available offline)."""
+import os
+import subprocess
+
+import numpy as np
+
+from superslam_amd import trajectory as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rot(axis, a):
+    c, s = np.cos(a), np.sin(a)
+    x, y, z = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+    return np.eye(3) + s * K + (1 - c) * K @ K
+
+
+def _drive(n=900, step=1.0):
+    """A KITTI-like drive: forward along the camera z axis with slow yaw, 1 m per frame."""
+    poses = [np.eye(4)]
+    for i in range(n):
+        d = np.eye(4)
+        d[:3, :3] = _rot([0, 1, 0], 0.004 * np.sin(i / 60.0))
+        d[2, 3] = step
+        poses.append(poses[-1] @ d)
+    return np.stack(poses)
+
+
+def test_kitti_and_tum_writers_match_the_reference_format(tmp_path):
+    gt = _drive(20)
+    p = tmp_path / "traj.txt"
+    T.save_trajectory_kitti(str(p), gt)
+    lines = open(p).read().splitlines()
+    assert len(lines) == 21 and all(len(l.split()) == 12 for l in lines)
+    assert lines[0] == "1.000000000 0.000000000 0.000000000 0.000000000 0.000000000 1.000000000 0.000000000 0.000000000 " \
+                       "0.000000000 0.000000000 1.000000000 0.000000000"      # std::fixed << setprecision(9)
+    np.testing.assert_allclose(T.load_kitti_poses(str(p)), gt, atol=5e-10)
+    q = tmp_path / "traj_tum.txt"
+    T.save_trajectory_tum(str(q), [0.1 * i for i in range(5)], gt)          # fewer timestamps than poses -> index fallback
+    rows = np.loadtxt(q)
+    assert rows.shape == (21, 8)
+    np.testing.assert_allclose(rows[:5, 0], [0, 0.1, 0.2, 0.3, 0.4], atol=1e-9)
+    assert rows[5, 0] == 5.0
+    np.testing.assert_allclose(np.linalg.norm(rows[:, 4:], axis=1), 1.0, atol=1e-8)
+    np.testing.assert_allclose(rows[0, 1:], [0, 0, 0, 0, 0, 0, 1], atol=1e-9)   # identity: q = (0, 0, 0, 1) as (x, y, z, w)
+    # quaternion of a 90 degree yaw about +y: (0, sin 45, 0, cos 45)
+    np.testing.assert_allclose(T.rotation_to_quaternion_xyzw(_rot([0, 1, 0], np.pi / 2)), [0, np.sqrt(0.5), 0, np.sqrt(0.5)], atol=1e-12)
+    np.testing.assert_allclose(np.abs(T.rotation_to_quaternion_xyzw(_rot([1, 0, 0], np.pi))), [1, 0, 0, 0], atol=1e-12)
+
+
+def test_cpp_writer_produces_the_same_file(tmp_path):
+    src = tmp_path / "w.cc"
+    src.write_text('#include "superslam_hip/trajectory.hpp"\nint main(int, char** a) { std::vector<superslam_hip::Pose3x4> p;'
+                   ' p.push_back({1, 0, 0, 0.5, 0, 1, 0, -1.25, 0, 0, 1, 3}); p.push_back({0, 0, 1, 1e-7, 0, 1, 0, 2, -1, 0, 0, 1.0 / 3});'
+                   ' return superslam_hip::save_trajectory_kitti(a[1], p) ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "w")])
+    subprocess.check_call([str(tmp_path / "w"), str(tmp_path / "cpp.txt")])
+    poses = np.array([[1, 0, 0, 0.5, 0, 1, 0, -1.25, 0, 0, 1, 3], [0, 0, 1, 1e-7, 0, 1, 0, 2, -1, 0, 0, 1.0 / 3]])
+    T.save_trajectory_kitti(str(tmp_path / "py.txt"), poses)
+    assert open(tmp_path / "cpp.txt").read() == open(tmp_path / "py.txt").read()
+
+
+def test_ate_is_invariant_to_a_rigid_motion_and_measures_noise():
+    gt = _drive(600)
+    # an estimate expressed in another world frame: ATE after alignment is exactly 0
+    G = np.eye(4); G[:3, :3] = _rot([0.3, -1, 0.2], 0.8); G[:3, 3] = [12.0, -3.0, 40.0]
+    est = np.einsum("ij,njk->nik", G, gt)
+    a = T.ate(gt, est)
+    assert a["rmse"] < 1e-9 and a["max"] < 1e-9
+    assert T.ate(gt, est, align=False)["rmse"] > 10.0
+    # isotropic position noise sigma per axis -> RMSE ~ sigma sqrt(3) (alignment absorbs ~6 of 1800 degrees of freedom)
+    rng = np.random.default_rng(0)
+    noisy = est.copy()
+    noisy[:, :3, 3] += rng.normal(0, 0.5, (len(gt), 3))
+    a = T.ate(gt, noisy)
+    assert abs(a["rmse"] - 0.5 * np.sqrt(3)) < 0.03
+    assert a["min"] <= a["median"] <= a["max"] and abs(a["sse"] - a["rmse"] ** 2 * len(gt)) < 1e-6
+    # a scale error is only removed by the Sim(3) alignment
+    scaled = gt.copy(); scaled[:, :3, 3] *= 1.05
+    assert T.ate(gt, scaled)["rmse"] > 1.0 and T.ate(gt, scaled, correct_scale=True)["rmse"] < 1e-9
+    R, t, s = T.umeyama(scaled[:, :3, 3], gt[:, :3, 3], with_scale=True)
+    assert abs(s - 1 / 1.05) < 1e-12 and np.allclose(R, np.eye(3), atol=1e-12)
+
+
+def test_kitti_segment_errors_on_known_drift():
+    gt = _drive(900)                                   # 900 m
+    k0 = T.kitti_segments(gt, gt)
+    assert k0["t_rel_percent"] < 1e-9 and k0["r_rel_deg_per_m"] < 1e-6
+    # 2 % scale drift: every segment's translation error is 2 % of its length (plus nothing from rotation)
+    est = gt.copy(); est[:, :3, 3] *= 1.02
+    k = T.kitti_segments(gt, est)
+    assert abs(k["t_rel_percent"] - 2.0) < 0.05 and k["r_rel_deg_per_m"] < 1e-9
+    # constant yaw drift of 0.01 deg per frame (= per metre here)
+    drift = [np.eye(4)]
+    for i in range(900):
+        d = np.linalg.inv(gt[i]) @ gt[i + 1]
+        e = np.eye(4); e[:3, :3] = _rot([0, 1, 0], np.radians(0.01))
+        drift.append(drift[-1] @ d @ e)
+    k = T.kitti_segments(gt, np.stack(drift))
+    assert abs(k["r_rel_deg_per_m"] - 0.01) < 5e-4 and k["t_rel_percent"] > 0.5
+    short = _drive(50)                                 # shorter than the smallest segment
+    assert np.isnan(T.kitti_segments(short, short)["t_rel_percent"])
