@@ -47,7 +47,7 @@ public:
   static Mat zeros(int r, int c, int type) { Mat m(r, c, type); if (m.data) std::memset(m.data, 0, m.step * r); return m; }
   void create(int r, int c, int type) {
     rows = r; cols = c; type_ = type; step = static_cast<size_t>(c) * elemSize();
-    own_ = std::shared_ptr<unsigned char>(new unsigned char[step * r ? step * r : 1], std::default_delete<unsigned char[]>());
+    own_ = std::shared_ptr<unsigned char>(new unsigned char[(step * r) != 0 ? step * r : 1], std::default_delete<unsigned char[]>());
     data = own_.get();
   }
   int type() const { return type_; }
