@@ -477,6 +477,23 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     out["deployed_unit"] = {"pairs_per_s": round(3 * CH * P / (time.perf_counter() - t2), 2),
                             "unit": "SuperPoint x2 + LightGlue(L,R) + LightGlue(L, previous keyframe L) per pair",
                             "keyframe_matches_last_call": int((m2 >= 0).sum().item())}
+    # ---- EigenPlaces global descriptor (once per keyframe on the loop-closure thread, not part of `value`) ----
+    from superslam_amd import EigenPlaces
+    from superslam_amd.weights import make_eigenplaces_weights
+
+    epp = os.path.join(wdir, "eigenplaces.safetensors")
+    save_ep = __import__("superslam_amd.weights", fromlist=["save_safetensors"]).save_safetensors
+    save_ep(make_eigenplaces_weights(2), epp)
+    ep = EigenPlaces(epp, 512, 512)
+    assert ep.initialize(), ep.last_error
+    ep.compute_global_descriptor(pairs[0][0])
+    t3 = time.perf_counter()
+    for _ in range(20):
+        ep.compute_global_descriptor(pairs[0][0])
+    ep_ms = (time.perf_counter() - t3) / 20 * 1e3
+    out["eigenplaces"] = {"ms_per_descriptor": round(ep_ms, 3), "includes": "host preprocess (resize to 512x512, normalise) + H2D + ResNet-18 + GeM + FC + D2H, synchronous",
+                          "gflop": 19.0, "input": [H, W]}
+    ep.close()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], K)
 

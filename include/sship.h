@@ -226,6 +226,25 @@ int sship_filter_matches(const int32_t* matches0, const float* mscores0, int n0,
 int sship_desc_to_host(const void* desc_dev, int count, int dim, float* out_f32);
 
 /* ------------------------------------------------------------------------------------------------
+ * EigenPlaces place recogniser - include/EigenPlaces.h:19-40, src/EigenPlaces.cc
+ * ResNet-18 trunk + L2Norm / GeM / Linear(512, 512) / L2Norm (utils/convert_eigenplaces_to_onnx.py:54-60), used once per
+ * keyframe by the loop-closure thread.  weights_path: safetensors of the hub model's state_dict (keys backbone.*,
+ * aggregation.*, what utils/convert_eigenplaces_to_onnx.py:99 saves) - it takes the place of the .engine file.
+ * sship_ep_infer is the device half of EigenPlaces::compute_global_descriptor (src/EigenPlaces.cc:147-174): the caller hands
+ * the HOST-preprocessed fp32 [3, input_h, input_w] tensor (src/EigenPlaces.cc:123-145 runs on the host in the reference too;
+ * include/superslam_hip/place_recognizer.hpp restates it) and receives the L2-normalised 512-d descriptor.  Synchronous.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sship_ep sship_ep;
+int sship_ep_create(const char* weights_path, int input_w, int input_h, sship_ep** out);
+void sship_ep_destroy(sship_ep* ep);
+int sship_ep_descriptor_dim(const sship_ep* ep);
+int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_out);
+/* EigenPlaces::preprocess (src/EigenPlaces.cc:123-145) on the host, no GPU: u8 image (1 channel or 3 = BGR, row stride in bytes) ->
+ * fp32 [3, input_h, input_w]: GRAY2RGB / BGR2RGB, cv::resize INTER_LINEAR (OpenCV's 8-bit fixed-point path), x 1/255,
+ * ImageNet mean / std.  Exported so that every binding shares one implementation. */
+int sship_ep_preprocess(const uint8_t* img, int h, int w, int stride, int channels, int input_w, int input_h, float* chw_out);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused front-end step: what StereoFrontEnd::process asks of the two interfaces per frame
  * (src/StereoFrontEnd.cc:14,33): SuperPoint on L and R (one batch) + gather x2 + one LightGlue match,
  * for `pairs` stereo pairs at once, device-resident, no host synchronisation.  imgs_dev is

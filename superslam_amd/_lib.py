@@ -76,6 +76,11 @@ _SIGS = {
     "sship_lg_debug_set_layers": (ip, [vp, ip]),
     "sship_lg_debug_read": (ip, [vp, ip, ip, ip, ip, vp]),
     "sship_filter_matches": (ip, [vp, vp, ip, vp, vp, vp]),
+    "sship_ep_create": (ip, [C.c_char_p, ip, ip, C.POINTER(vp)]),
+    "sship_ep_destroy": (None, [vp]),
+    "sship_ep_descriptor_dim": (ip, [vp]),
+    "sship_ep_infer": (ip, [vp, vp, vp]),
+    "sship_ep_preprocess": (ip, [vp, ip, ip, ip, ip, ip, ip, vp]),
     "sship_desc_to_host": (ip, [vp, ip, ip, vp]),
     "sship_frontend_batch_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp, vp]),
     "sship_sp_bench_layer": (ip, [vp, ip, ip, ip, ip, ip, C.POINTER(fp), C.POINTER(C.c_double)]),

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/sship.h"
+#include "../../include/superslam_hip/place_recognizer.hpp"
 #include "kernels.h"
 
 namespace sship {
@@ -177,6 +178,10 @@ static bool load_safetensors(const std::string& path, StateDict& sd, std::string
       else if (dtype == "F16" && off1 - off0 == n * 2) {
         const uint16_t* h = reinterpret_cast<const uint16_t*>(blob.data() + off0);
         for (size_t k = 0; k < n; ++k) t.data[k] = half_bits_to_float(h[k]);
+      } else if (dtype == "I64" || dtype == "I32" || dtype == "U8" || dtype == "BOOL" || dtype == "I16" || dtype == "I8") {
+        skip_ws();
+        if (i < js.size() && js[i] == ',') ++i;
+        continue;  // bookkeeping tensors (BatchNorm.num_batches_tracked ...): not weights
       } else { err = "tensor '" + name + "': unsupported dtype " + dtype; return false; }
       sd[name] = std::move(t);
     }
@@ -1498,6 +1503,140 @@ extern "C" int sship_filter_matches(const int32_t* matches0, const float* mscore
     ++k;
   }
   return k;
+}
+
+// ====================================================================================================
+// EigenPlaces place recogniser: include/EigenPlaces.h:19-40, src/EigenPlaces.cc:47-174
+// ====================================================================================================
+struct sship_ep {
+  int in_w = 0, in_h = 0;
+  hipStream_t stream = nullptr;
+  ConvW stem;
+  struct Block { ConvW c1, c2, ds; bool has_ds = false; int stride = 1; } blocks[8];
+  float* fc_wt = nullptr;   // [in 512][out 512] fp32 (transposed)
+  float* fc_b = nullptr;
+  float gem_p = 3.f;
+  DevBuf d_in, patches, act[4], d_out;
+  PinBuf h_out;
+};
+extern "C" void sship_ep_destroy(sship_ep* ep) {
+  bind_thread();
+  if (!ep) return;
+  (void)hipDeviceSynchronize();
+  free_conv(ep->stem);
+  for (auto& b : ep->blocks) { free_conv(b.c1); free_conv(b.c2); free_conv(b.ds); }
+  if (ep->fc_wt) (void)hipFree(ep->fc_wt);
+  if (ep->fc_b) (void)hipFree(ep->fc_b);
+  if (ep->stream) (void)hipStreamDestroy(ep->stream);
+  delete ep;
+}
+extern "C" int sship_ep_create(const char* weights_path, int input_w, int input_h, sship_ep** out) {
+  bind_thread();
+  if (!weights_path || !out || input_w < 32 || input_h < 32) return fail(SSHIP_ERR_INVALID, "ep_create: bad arguments");
+  if (int rc = require_device()) return rc;
+  StateDict sd; std::string err;
+  if (!load_safetensors(weights_path, sd, err)) return fail(SSHIP_ERR_IO, err);
+  std::unique_ptr<sship_ep, void (*)(sship_ep*)> ep(new sship_ep(), sship_ep_destroy);
+  ep->in_w = input_w; ep->in_h = input_h;
+  // conv + BatchNorm (eval) folded: w' = w * g / sqrt(var + 1e-5), b' = beta - mean * g / sqrt(var + 1e-5)
+  auto folded = [&](const std::string& conv, const std::string& bn, int cout, int cin, int ks, int cin_pad, ConvW& dst) -> int {
+    const Tensor* w = find_tensor(sd, conv + ".weight", {cout, cin, ks, ks}, err);
+    const Tensor* g = w ? find_tensor(sd, bn + ".weight", {cout}, err) : nullptr;
+    const Tensor* be = g ? find_tensor(sd, bn + ".bias", {cout}, err) : nullptr;
+    const Tensor* mu = be ? find_tensor(sd, bn + ".running_mean", {cout}, err) : nullptr;
+    const Tensor* var = mu ? find_tensor(sd, bn + ".running_var", {cout}, err) : nullptr;
+    if (!var) return fail(SSHIP_ERR_IO, err);
+    const int kk = ks * ks;
+    const bool flat = cin_pad != cin;  // the stem: [cout][cin*ks*ks] rows zero-padded to cin_pad, run as a 1x1 GEMM
+    std::vector<float> wf((size_t)cout * (flat ? cin_pad : cin * kk), 0.f), bf(cout);
+    for (int co = 0; co < cout; ++co) {
+      const float sc = g->data[co] / sqrtf(var->data[co] + 1e-5f);
+      bf[co] = be->data[co] - mu->data[co] * sc;
+      for (int i = 0; i < cin * kk; ++i) wf[(size_t)co * (flat ? cin_pad : cin * kk) + i] = w->data[(size_t)co * cin * kk + i] * sc;
+    }
+    return upload_conv(wf.data(), bf.data(), cout, flat ? cin_pad : cin, flat ? 1 : ks, 64, dst);
+  };
+  if (int rc = folded("backbone.0", "backbone.1", 64, 3, 7, 192, ep->stem)) return rc;
+  const int planes[4] = {64, 128, 256, 512};
+  int cin = 64;
+  for (int L = 0; L < 4; ++L)
+    for (int b = 0; b < 2; ++b) {
+      sship_ep::Block& blk = ep->blocks[L * 2 + b];
+      const std::string p = "backbone." + std::to_string(4 + L) + "." + std::to_string(b);
+      const int c_in = b == 0 ? cin : planes[L];
+      blk.stride = (b == 0 && L > 0) ? 2 : 1;
+      if (int rc = folded(p + ".conv1", p + ".bn1", planes[L], c_in, 3, c_in, blk.c1)) return rc;
+      if (int rc = folded(p + ".conv2", p + ".bn2", planes[L], planes[L], 3, planes[L], blk.c2)) return rc;
+      if (b == 0 && (blk.stride != 1 || c_in != planes[L])) {
+        blk.has_ds = true;
+        if (int rc = folded(p + ".downsample.0", p + ".downsample.1", planes[L], c_in, 1, c_in, blk.ds)) return rc;
+      }
+      if (b == 1) cin = planes[L];
+    }
+  {
+    const Tensor* gp = find_tensor(sd, "aggregation.1.p", {1}, err);
+    const Tensor* w = gp ? find_tensor(sd, "aggregation.3.weight", {512, 512}, err) : nullptr;
+    const Tensor* bb = w ? find_tensor(sd, "aggregation.3.bias", {512}, err) : nullptr;
+    if (!bb) return fail(SSHIP_ERR_IO, err);
+    ep->gem_p = gp->data[0];
+    std::vector<float> wt((size_t)512 * 512);
+    for (int j = 0; j < 512; ++j)
+      for (int c = 0; c < 512; ++c) wt[(size_t)c * 512 + j] = w->data[(size_t)j * 512 + c];
+    if (int rc = upload_floats(wt.data(), wt.size(), &ep->fc_wt)) return rc;
+    if (int rc = upload_floats(bb->data.data(), 512, &ep->fc_b)) return rc;
+  }
+  const int Ho = (input_h - 1) / 2 + 1, Wo = (input_w - 1) / 2 + 1;
+  SSHIP_HIP_CHECK(ep->d_in.ensure((size_t)3 * input_h * input_w * 4));
+  SSHIP_HIP_CHECK(ep->patches.ensure((size_t)Ho * Wo * 192 * 2));
+  for (auto& a : ep->act) SSHIP_HIP_CHECK(a.ensure((size_t)Ho * Wo * 64 * 2));
+  SSHIP_HIP_CHECK(ep->d_out.ensure(512 * 4));
+  SSHIP_HIP_CHECK(ep->h_out.ensure(512 * 4));
+  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&ep->stream, hipStreamDefault));
+  *out = ep.release();
+  return SSHIP_OK;
+}
+extern "C" int sship_ep_descriptor_dim(const sship_ep* ep) { return ep ? 512 : 0; }
+// host half of compute_global_descriptor (no GPU involved): include/superslam_hip/place_recognizer.hpp
+extern "C" int sship_ep_preprocess(const uint8_t* img, int h, int w, int stride, int channels, int input_w, int input_h, float* chw_out) {
+  if (!img || !chw_out || h <= 0 || w <= 0 || input_w <= 0 || input_h <= 0 || (channels != 1 && channels != 3) || stride < w * channels)
+    return fail(SSHIP_ERR_INVALID, "ep_preprocess: bad arguments");
+  superslam_hip::eigenplaces_preprocess(superslam_hip::Image{img, h, w, channels, stride}, input_w, input_h, chw_out);
+  return SSHIP_OK;
+}
+extern "C" int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_out) {
+  bind_thread();
+  if (!ep || !chw_host || !desc_out) return fail(SSHIP_ERR_INVALID, "ep_infer: null argument");
+  hipStream_t s = ep->stream;
+  const int H = ep->in_h, W = ep->in_w;
+  SSHIP_HIP_CHECK(hipMemcpyAsync(ep->d_in.p, chw_host, (size_t)3 * H * W * 4, hipMemcpyHostToDevice, s));
+  int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
+  launch_ep_im2col(ep->d_in.as<float>(), H, W, h, w, ep->patches.as<_Float16>(), s);
+  _Float16* a[4] = {ep->act[0].as<_Float16>(), ep->act[1].as<_Float16>(), ep->act[2].as<_Float16>(), ep->act[3].as<_Float16>()};
+  SSHIP_HIP_CHECK(ep_conv(ep->stem, ep->patches.as<_Float16>(), a[0], nullptr, h, w, true, false, s));
+  const int hp = (h - 1) / 2 + 1, wp = (w - 1) / 2 + 1;  // MaxPool2d(3, 2, 1)
+  launch_ep_maxpool(a[0], h, w, hp, wp, a[1], s);
+  h = hp; w = wp;
+  int cur = 1;  // index of the buffer holding the block input
+  for (const auto& blk : ep->blocks) {
+    int f[3], k = 0;
+    for (int i = 0; i < 4; ++i) if (i != cur) f[k++] = i;  // three free buffers: t, ds, out
+    const _Float16* res = a[cur];
+    int ho = h, wo = w;
+    if (blk.stride == 2) { ho = (h + 1) / 2; wo = (w + 1) / 2; }
+    SSHIP_HIP_CHECK(ep_conv(blk.c1, a[cur], a[f[0]], nullptr, h, w, true, blk.stride == 2, s));
+    if (blk.has_ds) {
+      SSHIP_HIP_CHECK(ep_conv(blk.ds, a[cur], a[f[1]], nullptr, h, w, false, blk.stride == 2, s));
+      res = a[f[1]];
+    }
+    SSHIP_HIP_CHECK(ep_conv(blk.c2, a[f[0]], a[f[2]], res, ho, wo, true, false, s));
+    cur = f[2]; h = ho; w = wo;
+  }
+  launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, ep->d_out.as<float>(), s);
+  SSHIP_HIP_CHECK(hipGetLastError());
+  SSHIP_HIP_CHECK(hipMemcpyAsync(ep->h_out.p, ep->d_out.p, 512 * 4, hipMemcpyDeviceToHost, s));
+  SSHIP_HIP_CHECK(hipStreamSynchronize(s));
+  memcpy(desc_out, ep->h_out.p, 512 * 4);
+  return SSHIP_OK;
 }
 
 // ====================================================================================================

@@ -81,6 +81,13 @@ void launch_desc_head_gather(const ConvW& db32, const _Float16* da, int Hc, int 
 hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int ostride, int B, int H, int W,
                           hipStream_t s);
 
+// ---- ep_kernels.hip : EigenPlaces (ResNet-18 + GeM) ----
+hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Float16* res, int H, int W, bool relu, bool decim,
+                   hipStream_t s);
+void launch_ep_im2col(const float* x, int H, int W, int Ho, int Wo, _Float16* out, hipStream_t s);
+void launch_ep_maxpool(const _Float16* in, int H, int W, int Ho, int Wo, _Float16* out, hipStream_t s);
+void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* out, hipStream_t s);
+
 // ---- lg_kernels.hip ----
 struct LgDims {
   int S;    // sequences (2 * pairs)

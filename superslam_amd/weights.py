@@ -136,6 +136,39 @@ def to_raw_checkpoint_keys(sd: dict) -> dict:
             for k, v in sd.items()}
 
 
+def make_eigenplaces_weights(seed: int = 2) -> dict:
+    """Seeded EigenPlaces(ResNet18, 512) state dict with the hub model's key layout (backbone = nn.Sequential of torchvision's
+    ResNet-18 children without avgpool / fc, aggregation = [L2Norm, GeM, Flatten, Linear, L2Norm]; oracle/eigenplaces_ref.py).
+    Conv weights are he-normal, BatchNorm statistics are near identity with a little spread so that folding them matters."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        sd[name + ".weight"] = (torch.randn((cout, cin, k, k), generator=g) * math.sqrt(2.0 / (cin * k * k))).contiguous()
+
+    def bn(name, c, gamma=1.0):
+        sd[name + ".weight"] = (gamma * (1.0 + 0.1 * torch.randn(c, generator=g))).contiguous()
+        sd[name + ".bias"] = (0.05 * torch.randn(c, generator=g)).contiguous()
+        sd[name + ".running_mean"] = (0.05 * torch.randn(c, generator=g)).contiguous()
+        sd[name + ".running_var"] = (1.0 + 0.2 * torch.rand(c, generator=g)).contiguous()
+        sd[name + ".num_batches_tracked"] = torch.tensor(1, dtype=torch.int64)
+
+    conv("backbone.0", 64, 3, 7); bn("backbone.1", 64)
+    cin = 64
+    for idx, planes, stride in ((4, 64, 1), (5, 128, 2), (6, 256, 2), (7, 512, 2)):
+        for b in range(2):
+            p = f"backbone.{idx}.{b}"
+            conv(p + ".conv1", planes, cin if b == 0 else planes, 3); bn(p + ".bn1", planes)
+            conv(p + ".conv2", planes, planes, 3); bn(p + ".bn2", planes, gamma=0.5)   # damped residual branch: activations stay O(1)
+            if b == 0 and (stride != 1 or cin != planes):
+                conv(p + ".downsample.0", planes, cin, 1); bn(p + ".downsample.1", planes)
+        cin = planes
+    sd["aggregation.1.p"] = torch.tensor([3.0])
+    w, b = _lin(g, 512, 512, gain=1.0, bias_scale=0.02)
+    sd["aggregation.3.weight"], sd["aggregation.3.bias"] = w, b
+    return sd
+
+
 def save_safetensors(sd: dict, path: str) -> None:
     from safetensors.torch import save_file
 

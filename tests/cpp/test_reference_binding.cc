@@ -11,7 +11,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "LightGlue.h"       // integration/reference_side (first on the include path)
+#include "EigenPlaces.h"     // integration/reference_side (first on the include path)
+#include "LightGlue.h"       // integration/reference_side
 #include "SuperPoint.h"      // integration/reference_side
 #include "StereoFrontEnd.h"  // /root/reference/include
 
@@ -111,6 +112,12 @@ static void cpu_checks() {
   MatchResult r = lg.match({cv::KeyPoint(1, 1, 1)}, DeviceDescriptors(), {cv::KeyPoint(1, 1, 1)}, DeviceDescriptors());
   CHECK(r.matches.empty());
   CHECK(lg.descriptors_to_host(DeviceDescriptors()).empty());
+  // the place recogniser adapter is a concrete superslam::IPlaceRecognizer with the reference's constructor
+  static_assert(std::is_base_of<IPlaceRecognizer, EigenPlaces>::value && !std::is_abstract<EigenPlaces>::value, "EigenPlaces adapter");
+  EigenPlaces ep("/nonexistent/eigenplaces.safetensors", 512, 512);
+  CHECK(!ep.initialize());
+  CHECK(ep.compute_global_descriptor(cv::Mat::zeros(64, 64, CV_8U)).empty());      // `if (!context_) return cv::Mat();`
+  CHECK(ep.query(cv::Mat::zeros(1, 512, CV_32F), 0, 5).empty());
 }
 
 static void gpu_checks(const char* spw, const char* lgw) {
@@ -170,9 +177,26 @@ static void gpu_checks(const char* spw, const char* lgw) {
   CHECK(sp.infer(bgr, kp, desc) && kp.size() == 600 && desc.rows == 600 && desc.cols == 256);
 }
 
+static void gpu_place_recognizer(const char* epw) {
+  EigenPlaces ep(epw, 512, 512);
+  CHECK(ep.initialize());
+  cv::Mat a = make_image(376, 1240, 3), b = make_image(376, 1240, 4);
+  cv::Mat da = ep.compute_global_descriptor(a), db = ep.compute_global_descriptor(b), da2 = ep.compute_global_descriptor(a);
+  CHECK(da.rows == 1 && da.cols == 512 && da.type() == CV_32F);
+  double n = 0, same = 0;
+  for (int i = 0; i < 512; ++i) { n += da.ptr<float>(0)[i] * da.ptr<float>(0)[i]; same += std::fabs(da.ptr<float>(0)[i] - da2.ptr<float>(0)[i]); }
+  CHECK(std::fabs(n - 1.0) < 1e-4 && same == 0.0);               // L2-normalised, deterministic
+  ep.add(0, da); ep.add(1, db);
+  std::vector<LoopCandidate> r = ep.query(da, 0, 5);
+  CHECK(!r.empty() && r.front().keyframe_id == 0u && r.front().score > 0.999f);
+  CHECK(ep.query(da, 2, 5).empty());                              // everything excluded as too recent
+  std::printf("binding/gpu: EigenPlaces adapter, self score %.6f, %zu candidates\n", r.empty() ? 0.f : r.front().score, r.size());
+}
+
 int main(int argc, char** argv) {
   cpu_checks();
   if (argc >= 3) gpu_checks(argv[1], argv[2]);
+  if (argc >= 4) gpu_place_recognizer(argv[3]);
   if (g_fail) { std::printf("%d check(s) failed\n", g_fail); return 1; }
   std::printf("reference binding: all checks passed (%s)\n", argc >= 3 ? "cpu + gpu" : "cpu");
   return 0;

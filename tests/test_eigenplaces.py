@@ -1,0 +1,147 @@
+"""EigenPlaces place recogniser: host preprocessing bit-exact against the oracle (CPU), the reference's
+PlaceRecognizer cases on the C++ and Python mirrors (CPU), the network on the GPU against the fp32 oracle.
+
+PARITY UNPINNED for the network and for cv::resize (oracle/eigenplaces_ref.py header): the hub model, torchvision and OpenCV are
+all absent; the restatement follows their published definitions."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eigenplaces_ref as E
+from superslam_amd.synth import make_frame
+from superslam_amd.weights import make_eigenplaces_weights, save_safetensors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "superslam_amd", "lib", "test_place_recognizer")
+
+
+def _build():
+    libdir = os.path.join(ROOT, "superslam_amd", "lib")
+    src = os.path.join(ROOT, "tests", "cpp", "test_place_recognizer.cc")
+    hdr = os.path.join(ROOT, "include", "superslam_hip", "place_recognizer.hpp")
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
+                               "-L" + libdir, "-lsuperslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return BIN
+
+
+@pytest.fixture(scope="module")
+def ep_weights(tmp_path_factory):
+    sd = make_eigenplaces_weights(2)
+    p = str(tmp_path_factory.mktemp("ep") / "eigenplaces_resnet18_512.safetensors")
+    save_safetensors(sd, p)
+    return sd, p
+
+
+def test_resize_known_answers():
+    """cv::resize INTER_LINEAR on u8, hand-checkable cases: identity size, exact 2x down-sampling (pixel-centre rule:
+    source coordinate (d + 0.5) * 2 - 0.5 = 2 d + 0.5 -> the mean of two neighbours), constant images."""
+    a = np.arange(48, dtype=np.uint8).reshape(6, 8) * 5
+    np.testing.assert_array_equal(E.resize_bilinear_u8(a, 6, 8)[:, :, 0], a)
+    half = E.resize_bilinear_u8(a, 3, 4)[:, :, 0]
+    exp = (a[0::2, 0::2].astype(int) + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) // 4
+    np.testing.assert_array_equal(half, exp)
+    c = np.full((7, 9, 3), 93, np.uint8)
+    assert (E.resize_bilinear_u8(c, 512, 512) == 93).all()
+    up = E.resize_bilinear_u8(np.array([[0, 100]], np.uint8), 1, 4)[0, :, 0]      # coordinates -0.25, 0.25, 0.75, 1.25
+    assert up.tolist() == [0, 25, 75, 100]
+
+
+@pytest.mark.parametrize("shape,ch", [((376, 1241), 1), ((480, 752), 1), ((120, 160), 3), ((700, 500), 3)])
+def test_library_preprocess_is_bit_exact_with_the_oracle(shape, ch):
+    from superslam_amd import eigenplaces as P
+
+    img = make_frame(shape[0], shape[1], 31) if ch == 1 else np.stack([make_frame(shape[0], shape[1], 31 + i, n_rects=20) for i in range(3)], -1)
+    got = P.preprocess(img, 512, 512)
+    ref = E.preprocess(img, 512, 512)
+    assert got.shape == (3, 512, 512)
+    np.testing.assert_array_equal(got, ref)
+    if ch == 1:
+        np.testing.assert_allclose((got[1] * 0.224 + 0.456) * 255, (got[0] * 0.229 + 0.485) * 255, atol=2e-4)   # gray -> R = G = B
+
+
+def test_place_recognizer_cases_cpp_and_python():
+    from superslam_amd import CosineDescriptorIndex, EigenPlaces, TemporalConsistencyVoter, _lib
+
+    _lib.lib()
+    out = subprocess.run([_build()], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
+
+    def desc(dim, seed, jitter=0.0):
+        d = np.zeros(dim, np.float32); d[seed % dim] = 1.0; d[(seed + 1) % dim] = 0.5 + jitter
+        return d
+
+    for Index, Voter in ((CosineDescriptorIndex, TemporalConsistencyVoter), (E.CosineDescriptorIndex, None)):
+        idx = Index(); idx.add(0, desc(16, 3)); idx.add(1, desc(16, 9))
+        res = idx.query(desc(16, 3, 0.01), 0, 5, 0.0)
+        assert res[0][0] == 0 and res[0][1] > 0.95 and (len(res) < 2 or res[1][1] < res[0][1])
+        idx = Index()
+        for i in range(5):
+            idx.add(i, desc(16, i))
+        assert all(k < 3 for k, _ in idx.query(desc(16, 4), 2, 5, 0.0))
+        assert idx.query(desc(16, 0), 5, 5, 0.0) == [] and Index().query(desc(16, 0), 0, 5, 0.0) == []
+        assert len(idx.query(desc(16, 0), 0, 2, -1.0)) <= 2 and all(s >= 0.99 for _, s in idx.query(desc(16, 0), 0, 10, 0.99))
+    v = TemporalConsistencyVoter(3, 2)
+    assert [v.vote((10, .9)), v.vote((11, .9)), v.vote((10, .9))] == [False, False, True]
+    v = TemporalConsistencyVoter(2, 1)
+    assert [v.vote((10, .9)), v.vote(None), v.vote((10, .9)), v.vote((99, .9)), v.vote((99, .9))] == [False, False, False, False, True]
+    ep = EigenPlaces("/nonexistent.safetensors", 512, 512)          # error conventions without a GPU / weights
+    assert not ep.initialize() and ep.compute_global_descriptor(np.zeros((8, 8), np.uint8)).size == 0
+
+
+def test_oracle_is_a_resnet18_trunk(ep_weights):
+    """Shape / structure checks of the restatement: 11.2 M backbone parameters + 0.26 M head, 16 x 16 x 512 feature map at
+    512 x 512, unit-norm output, fp64 == fp32 within float accuracy."""
+    sd, _ = ep_weights
+    nb = sum(v.numel() for k, v in sd.items() if k.startswith("backbone.") and v.is_floating_point() and "running" not in k)
+    assert nb == 11176512      # torchvision resnet18 conv + bn affine parameters without the fc layer
+    x = torch.from_numpy(E.preprocess(make_frame(376, 1241, 3), 512, 512))[None]
+    out, feat = E.forward(sd, x, return_internals=True)
+    assert tuple(feat.shape) == (1, 512, 16, 16) and tuple(out.shape) == (1, 512)
+    assert abs(float(out.norm()) - 1.0) < 1e-5
+    out64 = E.forward(sd, x, dtype=torch.float64)
+    np.testing.assert_allclose(out.numpy(), out64.float().numpy(), atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_global_descriptor_vs_oracle(ep_weights, parity_report):
+    from superslam_amd import EigenPlaces
+
+    sd, path = ep_weights
+    ep = EigenPlaces(path, 512, 512)
+    assert ep.initialize(), ep.last_error
+    worst, descs = 0.0, []
+    for seed, shape in ((3, (376, 1241)), (4, (376, 1241)), (5, (480, 752))):
+        img = make_frame(shape[0], shape[1], seed)
+        d = ep.compute_global_descriptor(img)
+        ref = E.compute_global_descriptor(sd, img, dtype=torch.float64)
+        assert d.shape == (512,) and abs(np.linalg.norm(d) - 1.0) < 1e-5
+        dmax = float(np.abs(d - ref).max())
+        cos = float(d @ ref)
+        # the random-weight descriptors of different images are nearly parallel (cos 0.999): compare the part that
+        # distinguishes images too - the residual against the mean direction must match in direction
+        descs.append((d, ref))
+        worst = max(worst, dmax)
+        print(f"EigenPlaces seed {seed}: max|d| {dmax:.2e} (|ref| max {np.abs(ref).max():.3f}), cosine {cos:.7f}")
+        assert dmax <= 2e-3 and cos >= 0.9999
+    (d0, r0), (d1, r1) = descs[0], descs[1]
+    dd, dr = d0 - d1, r0 - r1
+    cdiff = float(dd @ dr / (np.linalg.norm(dd) * np.linalg.norm(dr)))
+    print(f"EigenPlaces difference-vector cosine (image A - image B, GPU vs oracle): {cdiff:.4f}")
+    parity_report["eigenplaces"] = {"max_abs_diff": worst, "difference_vector_cosine": cdiff}
+    assert cdiff >= 0.98
+    # index round trip + C++ mirror gives the same descriptor as the Python mirror
+    ep.add(7, descs[0][0])
+    assert ep.query(descs[0][0], 0, 5)[0][0] == 7
+    out = subprocess.run([_build(), path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("DESC")][0]
+    dc = np.array(line.split()[1:], np.float32)
+    H, W = 376, 1241
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = ((xx * 7 + yy * 13 + ((xx // 40 + yy // 30) % 5) * 37) & 255).astype(np.uint8)
+    np.testing.assert_allclose(dc, ep.compute_global_descriptor(img), atol=1e-6)
+    ep.close()

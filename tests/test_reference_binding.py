@@ -15,7 +15,7 @@ BIN = os.path.join(ROOT, "superslam_amd", "lib", "test_reference_binding")
 def build(force=False):
     libdir = os.path.join(ROOT, "superslam_amd", "lib")
     srcs = [os.path.join(ROOT, "tests", "cpp", "test_reference_binding.cc"), os.path.join(REF, "src", "StereoFrontEnd.cc")]
-    deps = srcs + [os.path.join(ROOT, "integration", "reference_side", f) for f in ("SuperPoint.h", "LightGlue.h")] + \
+    deps = srcs + [os.path.join(ROOT, "integration", "reference_side", f) for f in ("SuperPoint.h", "LightGlue.h", "EigenPlaces.h")] + \
         [os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp"), os.path.join(ROOT, "tests", "cpp", "shim", "opencv4", "opencv2", "core.hpp")]
     if force or not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function",
@@ -44,7 +44,11 @@ def test_binding_runs_the_reference_front_end_on_the_gpu(weights_dir):
         if not os.path.isdir(REF):
             pytest.fail("superslam_amd/lib/test_reference_binding is missing: __graft_entry__.build() produces it in the build container")
         build()
-    out = subprocess.run([BIN, weights_dir["sp_path"], weights_dir["lg_path"]], capture_output=True, text=True, timeout=300)
+    from superslam_amd.weights import make_eigenplaces_weights, save_safetensors
+
+    ep_path = os.path.join(weights_dir["dir"], "eigenplaces.safetensors")
+    save_safetensors(make_eigenplaces_weights(2), ep_path)
+    out = subprocess.run([BIN, weights_dir["sp_path"], weights_dir["lg_path"], ep_path], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr[-2000:])
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed (cpu + gpu)" in out.stdout
