@@ -36,6 +36,10 @@
 #ifndef SSHIP_PP_TRACE_BUILD
 #define SSHIP_PP_TRACE_BUILD 0
 #endif
+// s_setprio level of the data-movement role (0 = off; the MFMA role runs at priority 0)
+#ifndef SSHIP_PP_PRIO
+#define SSHIP_PP_PRIO 2
+#endif
 
 namespace sship {
 
@@ -230,8 +234,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     a1a0 = *reinterpret_cast<const h8_t*>(p.w1a + lane * 8);
     a1a1 = *reinterpret_cast<const h8_t*>(p.w1a + 512 + lane * 8);
   }
+  bool tr_stage = false;  // set by the half-step loop for the traced half-steps (SSHIP_PP_TRACE_BUILD)
   auto stage_conv1a = [&](int item) {
     if constexpr (FUSE1A) {
+      unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+      if (SSHIP_PP_TRACE_BUILD && tr_stage) ts0 = __builtin_readcyclecounter();
       int b, y0, x0;
       tile_coords(tile_of(item), b, y0, x0);
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         bf[k][6] = hh ? (_Float16)0.f : t[2][0];
         bf[k][7] = hh ? (_Float16)0.f : t[2][1];
       }
+      if (SSHIP_PP_TRACE_BUILD && tr_stage) ts1 = __builtin_readcyclecounter();
       f16x_t d0[NT_W], d1[NT_W];
 #pragma unroll
       for (int k = 0; k < NT_W; ++k) {
@@ -278,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         d0[k] = mfma32(a1a0, bf[k], d0[k]);
         d1[k] = mfma32(a1a1, bf[k], d1[k]);
       }
+      if (SSHIP_PP_TRACE_BUILD && tr_stage) ts2 = __builtin_readcyclecounter();
 #pragma unroll
       for (int k = 0; k < NT_W; ++k) {
         if (gw + 4 * k >= P_NT1A) continue;
@@ -301,6 +310,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
             *reinterpret_cast<h4_t*>(my_in + base + (u0 ^ 32)) = o1;
           }
         }
+      }
+      if (SSHIP_PP_TRACE_BUILD && tr_stage) {
+        unsigned long long* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10;
+        o[6] = ts1 - ts0; o[7] = ts2 - ts1; o[8] = __builtin_readcyclecounter() - ts2;
       }
     }
   };
@@ -412,8 +425,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     const bool tr = SSHIP_PP_TRACE_BUILD && p.trace && (s == 8 || s == 9) && gw == 0 && lane == 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (tr) t0 = __builtin_readcyclecounter();
+    tr_stage = tr;
     if (((s + 1) & 1) == grp) {
       // ---- data-movement role: epilogue of the item whose MFMA just finished, stage the next item, prefetch ----
+      // Static priority for the role (SSHIP_PP_PRIO, default on): this wave shares its SIMD with a wave that has 72-144 MFMAs ready
+      // back to back; at equal priority the older wave wins arbitration, and this role's few instructions (conv1a's six MFMAs, the
+      // LDS writes, the prefetch loads) queue behind that stream - the role trace had `stage` at 4.8 k clocks for ~1 k of work.
+      if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(SSHIP_PP_PRIO);
       const int w_done = (s - 1 - grp) >> 1;  // item whose MFMA ran in half-step s - 1
       if (s - 1 - grp >= 0 && w_done < NW && (w_done % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w_done, EPI_MFMA, 2 * MT);
       if (tr) t1 = __builtin_readcyclecounter();
@@ -425,10 +443,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       }
       if (tr) {
         t3 = __builtin_readcyclecounter();
-        unsigned long long* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 6;
+        unsigned long long* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10;
         o[0] = t1 - t0; o[1] = t2 > t1 ? t2 - t1 : 0; o[2] = t2 ? t3 - t2 : 0;
       }
     } else {
+      if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(0);
       const int w = (s - grp) >> 1;
       if (s - grp >= 0 && w < NW && !(p.dbg & 4)) {
         mfma_item(w);
@@ -436,11 +455,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         // half-step (epilogue + staging + prefetch) is the longer of the two roles, this group would only wait for it
         if (EPI_MFMA > 0 && (w % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w, 0, EPI_MFMA);
       }
-      if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 6 + 3] = __builtin_readcyclecounter() - t0;
+      if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10 + 3] = __builtin_readcyclecounter() - t0;
     }
     if (tr) t1 = __builtin_readcyclecounter();
     __syncthreads();
-    if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 6 + 4 + (((s + 1) & 1) == grp ? 0 : 1)] = __builtin_readcyclecounter() - t1;
+    if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10 + 4 + (((s + 1) & 1) == grp ? 0 : 1)] = __builtin_readcyclecounter() - t1;
   }
 }
 
@@ -464,23 +483,24 @@ static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
   static const bool trace_on = SSHIP_PP_TRACE_BUILD && getenv("SSHIP_PP_TRACE") != nullptr;
   static unsigned long long* tbuf = nullptr;
   if (trace_on) {
-    if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 2 * 6 * 8);
-    (void)hipMemsetAsync(tbuf, 0, 4096 * 2 * 6 * 8, s);
+    if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 2 * 10 * 8);
+    (void)hipMemsetAsync(tbuf, 0, 4096 * 2 * 10 * 8, s);
     a.trace = tbuf;
   }
   hipLaunchKernelGGL(kern, dim3(gx, ncb), dim3(512), smem, s, a);
   if (trace_on) {
-    std::vector<unsigned long long> h(4096 * 2 * 6);
+    std::vector<unsigned long long> h(4096 * 2 * 10);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
-    double sum[6] = {0}; long cnt = 0;
+    double sum[10] = {0}; long cnt = 0;
     for (int i = 0; i < gx * ncb * 2; ++i) {
-      if (!h[i * 6 + 3]) continue;
-      for (int k = 0; k < 6; ++k) sum[k] += (double)h[i * 6 + k];
+      if (!h[i * 10 + 3]) continue;
+      for (int k = 0; k < 10; ++k) sum[k] += (double)h[i * 10 + k];
       ++cnt;
     }
     if (cnt) fprintf(stderr, "[pp trace cin=%d ct=%d pool=%d fuse=%d] epilogue=%.0f stage=%.0f prefetch=%.0f | mfma=%.0f | barrier wait after data=%.0f after mfma=%.0f (clk, %ld groups)\n",
                      CIN, CT, (int)POOL, (int)FUSE1A, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, cnt);
+    if (cnt && sum[6] > 0) fprintf(stderr, "[pp trace   conv1a staging] convert=%.0f mfma issue=%.0f relu+lds writes=%.0f clk\n", sum[6] / cnt, sum[7] / cnt, sum[8] / cnt);
   }
   return hipGetLastError();
 }
