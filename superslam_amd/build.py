@@ -10,14 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsuperslam_hip.so")
-SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip"]
+SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "conv_pp128.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 # per-file flags.  -fno-honor-nans: under IEEE NaN semantics every fmaxf() operand that comes out of an MFMA is
 # canonicalised first (a second v_max_f32 per value) - the attention softmax's running max and every ReLU / max-pool
 # of the conv epilogues paid for that.  None of these kernels produces or tests for a NaN (masked scores are -inf,
 # never inf - inf); infinities keep their meaning.
-FILE_FLAGS = {f: ["-fno-honor-nans"] for f in ("lg_kernels.hip", "conv_pp.hip", "conv_strip.hip", "sp_convs.hip")}
+FILE_FLAGS = {f: ["-fno-honor-nans"] for f in ("lg_kernels.hip", "conv_pp.hip", "conv_pp128.hip", "conv_strip.hip", "sp_convs.hip")}
 
 
 def _newest(paths):

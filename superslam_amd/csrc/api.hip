@@ -209,6 +209,8 @@ static const Tensor* find_tensor(const StateDict& sd, const std::string& name, s
 // tile_interleave: M-tile mt of row block cb holds logical rows (mt * nblocks + cb) * 32 .. + 31 instead of
 // cb * ct + mt * 32 .. (the fused projection of the LightGlue FFN kernel: every wave then owns one 32-row tile of
 // EACH of the q / k / v segments, so all waves have the same epilogue work).  The bias stays in logical order.
+static std::vector<_Float16> pack_conv(const float* w, int cout, int cin, int ks, int ct, int chunk, const std::vector<int>* row_map,
+                                       const std::vector<float>* row_scale, bool tile_interleave);
 static int upload_conv(const float* w, const float* bias, int cout, int cin, int ks, int ct, ConvW& out,
                        const std::vector<int>* row_map = nullptr, const std::vector<float>* row_scale = nullptr,
                        bool tile_interleave = false) {
@@ -258,8 +260,42 @@ static int upload_conv(const float* w, const float* bias, int cout, int cin, int
 }
 static void free_conv(ConvW& c) {
   if (c.w) (void)hipFree(c.w);
+  if (c.w_q) (void)hipFree(c.w_q);
   if (c.bias) (void)hipFree(c.bias);
-  c.w = nullptr; c.bias = nullptr;
+  c.w = nullptr; c.w_q = nullptr; c.bias = nullptr;
+}
+// the same fragment order with a K chunk of `chunk` channels: [cout_blk][cin / chunk][ky][kx][k-step chunk / 16][m-tile][lane][8]
+static std::vector<_Float16> pack_conv(const float* w, int cout, int cin, int ks, int ct, int chunk, const std::vector<int>* row_map,
+                                       const std::vector<float>* row_scale, bool /*tile_interleave*/) {
+  const int cout_pad = (cout + ct - 1) / ct * ct, mt_n = ct / 32;
+  std::vector<_Float16> pk((size_t)cout_pad * cin * ks * ks);
+  size_t o = 0;
+  for (int cb = 0; cb < cout_pad / ct; ++cb)
+    for (int ch = 0; ch < cin / chunk; ++ch)
+      for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx)
+          for (int kstep = 0; kstep < chunk / 16; ++kstep)
+            for (int mt = 0; mt < mt_n; ++mt)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                  const int co = cb * ct + mt * 32 + (lane & 31);
+                  const int ci = ch * chunk + kstep * 16 + (lane >> 5) * 8 + e;
+                  float v = 0.f;
+                  if (co < cout) {
+                    const int src = row_map ? (*row_map)[co] : co;
+                    v = w[(((size_t)src * cin + ci) * ks + ky) * ks + kx];
+                    if (row_scale) v *= (*row_scale)[co];
+                  }
+                  pk[o++] = (_Float16)v;
+                }
+  return pk;
+}
+// second packing of a 128-input-channel 3x3 layer for conv_pp128.hip (64-row cout tiles, 32-channel chunks)
+static int upload_conv_q(const float* w, int cout, int cin, ConvW& out) {
+  const std::vector<_Float16> pk = pack_conv(w, cout, cin, 3, 64, 32, nullptr, nullptr, false);
+  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.w_q), pk.size() * sizeof(_Float16)));
+  SSHIP_HIP_CHECK(hipMemcpy(out.w_q, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  return SSHIP_OK;
 }
 static int upload_floats(const float* src, size_t n, float** dst) {
   *dst = nullptr;
@@ -695,6 +731,8 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
     const Tensor* b = w ? find_tensor(sd, std::string(l.name) + ".bias", {l.cout}, err) : nullptr;
     if (!w || !b) return fail(SSHIP_ERR_IO, err);
     if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, l.ks, l.ct, *l.dst)) return rc;
+    if (l.ks == 3 && l.cin == 128 && std::string(l.name) != "convDa")   // convDa keeps the k order the sparse descriptor head shares
+      if (int rc = upload_conv_q(w->data.data(), l.cout, l.cin, *l.dst)) return rc;
     if (std::string(l.name) == "convDb")
       if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, 1, 32, sp->cDb32)) return rc;
   }

@@ -18,6 +18,7 @@
 //   prefetched into registers two half-steps earlier; no LDS patch, no extra barrier.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "igemm.h"
@@ -509,6 +510,10 @@ hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int 
   PpArgs a{};
   a.in = in; a.wpack = w.w; a.bias = w.bias; a.out = out; a.B = B; a.H = H; a.W = W; a.cout = w.cout;
   if (w.cin == 64 && w.ct == 64) return pool ? launch_pp<64, 64, true, false>(a, s) : launch_pp<64, 64, false, false>(a, s);
+  // 128 input channels: the 64-row-tile kernel over 32-channel chunks (conv_pp128.hip) when the layer carries that packing;
+  // SUPERSLAM_HIP_CONV128=ct32 keeps the 32-row-tile kernel of this file (A/B runs)
+  static const bool ct32 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV128"); return e && std::string(e) == "ct32"; }();
+  if (w.cin == 128 && w.w_q && !ct32 && sp_conv3x3_pp128_fits(B, H, W)) return sp_conv3x3_pp128(w, in, out, B, H, W, pool, s);
   if (w.cin == 128 && w.ct == 32) return pool ? launch_pp<128, 32, true, false>(a, s) : launch_pp<128, 32, false, false>(a, s);
   return hipErrorInvalidValue;
 }

@@ -1,0 +1,410 @@
+// Ping-pong 3x3 convolution for the 128-input-channel layers of SuperPoint (conv3b, conv4a, conv4b, convPa;
+// utils/convert_superpoint_to_onnx.py:41-46) with a 64-row cout tile.
+//
+// conv_pp.hip keeps all weights of a workgroup's cout tile in LDS (72 KiB); with 128 input channels that allowed only a
+// 32-row tile: one M-tile per wave (1.5 LDS fragment reads per MFMA), every input tile staged by four workgroups.
+// Here the K dimension runs in 32-channel chunks:
+//   * weights of ONE chunk for 64 output rows are 36 KiB ([tap 9][k-step 2][m-tile 2][lane][8]); two such slots form a ring
+//     that is refilled by LDS-DMA (global_load_lds_dwordx4) two half-steps ahead: both wave groups use chunk c in consecutive
+//     half-steps, then the slot is free for chunk c + 2;
+//   * an input tile chunk is 10 x 34 px x 32 ch = 21.8 KB, staged by cout / 64 workgroups instead of cout / 32;
+//   * a work item (tile, chunk) is 72 MFMAs per wave (9 taps x 2 k-steps x 2 M-tiles x 2 N-tiles), with two A and two
+//     B fragments per k-step (1.0 LDS fragment reads per MFMA).
+// Pixel rows are 64 bytes in LDS (4 sixteen-byte units); unit u of column c sits in slot u ^ ((c >> 2) & 3): the 16 lanes of
+// a ds_read_b128 group cover 16 consecutive columns mod 16, i.e. every (c & 3, slot) pair once = 64 distinct banks.
+//
+// The data-movement role of the ping-pong scheme shares every SIMD with a wave that has 72 MFMAs queued; the role trace
+// (profiles/r02_pp_role_trace.txt) shows it pays ~10 clocks per VALU instruction there, so its cost is its instruction count,
+// not its bytes.  This kernel keeps that count small:
+//   * staging addresses are affine: thread t of a 256-thread group owns unit t of the 272 units of halo-row pair i (i = 0..4),
+//     so one VGPR offset + a scalar per-pair offset addresses all five loads (buffer_load ... soffset) and one LDS address +
+//     an immediate all five ds_write_b128; the 16 left-over units per pair are a sixth load of threads 0..79;
+//   * out-of-image halo pixels are not masked after the fact: their voffset is pushed out of the buffer's range, the load
+//     returns zeros (edge tiles only: two compares per load);
+//   * tile coordinates are walked incrementally in scalar registers (no division per item);
+//   * the bias initialises the accumulators, ReLU runs on packed fp16 after the conversion (rounding is monotone and keeps
+//     the sign: relu(fp16(x)) == fp16(relu(x))), the pooled variant uses max3.
+// Roles and the half-step schedule are those of conv_pp.hip; the MFMA group writes its own epilogue after a tile's last chunk.
+#include "igemm.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#ifndef SSHIP_PP_PRIO
+#define SSHIP_PP_PRIO 2
+#endif
+#ifndef SSHIP_PP_TRACE_BUILD
+#define SSHIP_PP_TRACE_BUILD 0  // role tracing (SSHIP_PP_TRACE=1 at run time), as in conv_pp.hip
+#endif
+
+namespace sship {
+
+struct Pp128Args {
+  const _Float16* in;     // channels-last fp16 [B,H,W,128]
+  const _Float16* wpack;  // packed [cout / 64][chunk 4][tap 9][k-step 2][m-tile 2][lane 64][8]
+  const float* bias;
+  _Float16* out;
+  int B, H, W, cout;
+  unsigned long long* trace;  // [workgroup][group][6] clocks of half-steps 8..9: weight DMA issue, stage, prefetch, mfma, barrier waits
+};
+
+constexpr int Q_TH = 8, Q_TW = 32, Q_THH = 10, Q_TWH = 34;
+constexpr int Q_IN_HALFS = Q_THH * Q_TWH * 32;  // 10,880 halfs = 21,760 B per wave group
+constexpr int Q_W_SLOT = 9 * 2 * 2 * 512;       // 18,432 halfs = 36,864 B: one (cout tile, chunk)
+constexpr int Q_ROW_UNITS = Q_TWH * 4;          // 136 sixteen-byte units per halo row
+constexpr int Q_NCHUNK = 4;
+constexpr unsigned Q_OOB = 0xfffffff0u;         // voffset beyond num_records: the buffer load returns zeros
+
+__device__ __forceinline__ int pp128_lds(int row, int col, int unit) {
+  return (row * Q_TWH + col) * 32 + ((unit ^ ((col >> 2) & 3)) << 3);
+}
+
+struct TileWalk { int tx, ty, b; };  // wave-uniform tile coordinates of a group's tile stream (stride 2 tiles)
+
+template <bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_pp128(Pp128Args p) {
+  constexpr int MT = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem128[];
+  _Float16* s_w = reinterpret_cast<_Float16*>(smem128);  // [2 slots][Q_W_SLOT]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+  const int gw = wave & 3, gt = tid & 255;
+  const int gw_u = __builtin_amdgcn_readfirstlane(gw);
+  _Float16* my_in = s_w + 2 * Q_W_SLOT + grp * Q_IN_HALFS;
+  float* s_bias = reinterpret_cast<float*>(s_w + 2 * Q_W_SLOT + 2 * Q_IN_HALFS);
+
+  const int tiles_x = (p.W + Q_TW - 1) / Q_TW, tiles_y = (p.H + Q_TH - 1) / Q_TH;
+  const int ntiles = p.B * tiles_x * tiles_y;
+  const int cb = blockIdx.y;
+  const int t_begin = (int)((long long)blockIdx.x * ntiles / gridDim.x);
+  const int t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  const int n_wg = t_end - t_begin;
+  if (n_wg <= 0) return;
+  const _Float16* wsrc = p.wpack + (size_t)cb * (Q_NCHUNK * Q_W_SLOT);
+
+  // chunk 0 -> slot 0 before the first half-step (plain copy by all 512 threads)
+  for (int u = tid; u < Q_W_SLOT / 8; u += 512) *reinterpret_cast<uint4*>(s_w + u * 8) = *reinterpret_cast<const uint4*>(wsrc + u * 8);
+  if (tid < 128) s_bias[tid] = p.bias[cb * 64 + (tid & 63)];  // two copies, one per N-tile (see mfma_item)
+  // half `half` (18 fragments of 1 KiB) of weight chunk `cn` -> ring slot cn & 1, by the four waves of a group: wave g moves
+  // fragments f0 .. f0 + n - 1 (f0 = 0, 5, 10, 14; n = 5, 5, 4, 4).  One scalar base address, one M0 (LDS base) and one lane
+  // offset VGPR per wave; fragments 1..3 ride on the instruction offset (applied to the global AND the LDS address), so M0
+  // changes once more at most - rewriting it between DMAs serialised them (traced: ~170 clocks per DMA instruction).
+  const unsigned lane16 = lane * 16;
+  const int dma_f0 = gw_u < 2 ? gw_u * 5 : 10 + (gw_u - 2) * 4;
+  auto fill_weights = [&](int cn, int half) __attribute__((always_inline)) {
+    const unsigned long long ga = (unsigned long long)(uintptr_t)(wsrc + (size_t)cn * Q_W_SLOT + (half * 18 + dma_f0) * 512);
+    const unsigned long long g = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ga) |
+                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ga >> 32)) << 32);  // uniform: say so
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(s_w + (cn & 1) * Q_W_SLOT + (half * 18 + dma_f0) * 512));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(g) : "memory");
+    if (gw_u < 2)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(lane16), "s"(dst + 4096), "s"(g + 4096) : "memory");
+  };
+  int boff[3][2];  // B fragment of column j + kx, k-step ksl: unit 2 ksl + hh
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) boff[kx][ksl] = (j + kx) * 32 + (((2 * ksl + hh) ^ (((j + kx) >> 2) & 3)) << 3);
+
+  auto walk_init = [&](int t) __attribute__((always_inline))  {
+    TileWalk w;
+    w.tx = t % tiles_x;
+    const int r = t / tiles_x;
+    w.ty = r % tiles_y; w.b = r / tiles_y;
+    return w;
+  };
+  auto walk_next = [&](TileWalk& w) __attribute__((always_inline))  {  // two tiles further along the (b, ty, tx) raster
+    w.tx += 2;
+    while (w.tx >= tiles_x) {
+      w.tx -= tiles_x;
+      if (++w.ty == tiles_y) { w.ty = 0; ++w.b; }
+    }
+  };
+  TileWalk pw = walk_init(t_begin + grp), ew = pw;  // tile of the next prefetch / of the next epilogue
+
+  // ---------------- staging geometry (tile-invariant, per thread) ----------------
+  // main part: unit gt of the 272 units of a halo-row pair; remainder: units 256..271 of pair (gt >> 4), threads 0..79
+  const int m_hi = gt >= Q_ROW_UNITS ? 1 : 0, m_v = gt - m_hi * Q_ROW_UNITS, m_px = m_v >> 2, m_part = m_v & 3;
+  const int r_row = 2 * (gt >> 4) + 1, r_px = 30 + ((gt & 15) >> 2), r_part = gt & 3;
+  const bool r_on = gt < 80;
+  const unsigned voff_main = (unsigned)((m_hi * p.W + m_px) * 256 + m_part * 16);
+  const unsigned voff_rem = r_on ? (unsigned)((r_row * p.W + r_px) * 256 + r_part * 16) : Q_OOB;
+  _Float16* lds_main = my_in + pp128_lds(m_hi, m_px, m_part);  // + i * (2 rows) for pair i
+  _Float16* lds_rem = my_in + pp128_lds(r_on ? r_row : 0, r_px, r_part);
+  const unsigned pair_bytes = (unsigned)(2 * p.W * 256);
+  // buffer over the whole input, based one row and one pixel before it: halo pixel (r, c) of tile (y0, x0) is at
+  // ((b H + y0) W + x0) * 256 + (r W + c) * 256 from there.  Every out-of-image access is masked by voffset (soffset takes no
+  // part in the range check), so num_records only has to exceed every valid voffset.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.in) - (size_t)(p.W + 1) * 256), 0, (int)0x7ffffff0, 0x00020000);
+
+  typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+  u4_t rin[2][6];  // two register sets: the prefetch of item w + 2 is issued before item w + 1 is written to LDS
+  auto prefetch_in = [&](int chunk, auto set_c) __attribute__((always_inline))  {
+    constexpr int set = decltype(set_c)::value;
+    const int y0 = pw.ty * Q_TH, x0 = pw.tx * Q_TW;
+    const unsigned soff = (unsigned)((pw.b * p.H + y0) * p.W + x0) * 256u + (unsigned)chunk * 64u;
+    const bool interior = y0 >= 1 && y0 + Q_TH + 1 <= p.H && x0 >= 1 && x0 + Q_TW + 1 <= p.W;
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) rin[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_main, soff + i * pair_bytes, 0);
+      rin[set][5] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_rem, soff, 0);
+    } else {
+      // halo row r is inside the image for rlo <= r <= rhi, halo column c for clo <= c <= chi
+      const int rlo = y0 == 0 ? 1 : 0, rhi = min(Q_THH - 1, p.H - y0), clo = x0 == 0 ? 1 : 0, chi = min(Q_TWH - 1, p.W - x0);
+      const bool m_ok = m_px >= clo && m_px <= chi;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int r = 2 * i + m_hi;
+        rin[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (m_ok && r >= rlo && r <= rhi) ? voff_main : Q_OOB, soff + i * pair_bytes, 0);
+      }
+      const bool r_ok = r_px >= clo && r_px <= chi && r_row >= rlo && r_row <= rhi;
+      rin[set][5] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, r_ok ? voff_rem : Q_OOB, soff, 0);
+    }
+    if (chunk == Q_NCHUNK - 1) walk_next(pw);
+  };
+  auto stage_in = [&](auto set_c) __attribute__((always_inline))  {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<u4_t*>(lds_main + i * (2 * Q_TWH * 32)) = rin[set][i];
+    if (r_on) *reinterpret_cast<u4_t*>(lds_rem) = rin[set][5];
+  };
+
+  f16x_t acc[MT][2];
+  // ---------------- MFMA half-step: 18 k-steps of one 32-channel chunk, fragments triple-buffered ----------------
+  // chunk 0 starts the accumulators from the bias (row 8 g + 4 hh + e of M-tile m is register 4 g + e), chunks 1..3
+  // accumulate in place: the accumulators are defined and consumed inside one tile iteration.
+  auto mfma_item = [&](auto chunk_c) __attribute__((always_inline))  {
+    constexpr int chunk = decltype(chunk_c)::value;
+    const _Float16* wc = s_w + (chunk & 1) * Q_W_SLOT + lane * 8;
+    const _Float16* ib = my_in + (gw * 2) * Q_TWH * 32;
+    h8_t fa[3][MT], fb[3][2];
+    auto load_frags = [&](int idx, int buf) __attribute__((always_inline))  {
+      const int tap = idx >> 1, ksl = idx & 1, ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[buf][m] = *reinterpret_cast<const h8_t*>(wc + (idx * MT + m) * 512);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) fb[buf][n] = *reinterpret_cast<const h8_t*>(ib + (n + ky) * Q_TWH * 32 + boff[kx][ksl]);
+    };
+    load_frags(0, 0);
+    load_frags(1, 1);
+    if constexpr (chunk == 0) {  // one LDS read per accumulator quad: the ds_read lands in the accumulator registers, no moves
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(s_bias + n * 64 + m * 32 + hh * 4 + g * 8);  // copy n: no CSE, no moves
+            acc[m][n][4 * g + 0] = b4.x; acc[m][n][4 * g + 1] = b4.y; acc[m][n][4 * g + 2] = b4.z; acc[m][n][4 * g + 3] = b4.w;
+          }
+    }
+#pragma unroll
+    for (int idx = 0; idx < 18; ++idx) {
+      if (idx + 2 < 18) load_frags(idx + 2, (idx + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(fa[idx % 3][m], fb[idx % 3][n], acc[m][n]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // ---------------- epilogue: ReLU (+ 2x2 max-pool) -> fp16 channels-last, 16-byte stores; the bias is already in ----------------
+  auto epilogue = [&]() __attribute__((always_inline))  {
+    const int y0 = ew.ty * Q_TH, x0 = ew.tx * Q_TW, b = ew.b;
+    walk_next(ew);
+    const int yb = y0 + gw * 2, x = x0 + j;
+    const h2_t z2 = {(_Float16)0.f, (_Float16)0.f};
+    auto relu2 = [&](float lo, float hi) __attribute__((always_inline))  -> unsigned {  // two values -> packed fp16, ReLU on the pair
+      h2_t v = {(_Float16)lo, (_Float16)hi};
+      v = __builtin_elementwise_max(v, z2);
+      return *reinterpret_cast<const unsigned*>(&v);
+    };
+    auto pack2 = [](float lo, float hi) -> unsigned {
+      const h2_t v = {(_Float16)lo, (_Float16)hi};
+      return *reinterpret_cast<const unsigned*>(&v);
+    };
+    // lanes hh = 0 / 1 hold channels 4 hh .. + 3 of an 8-channel unit: permlane32_swap pairs them into one 16-byte store each
+    auto store_pair = [&](_Float16* pix, int m, int g, unsigned a0, unsigned a1, unsigned b0, unsigned b1, bool ok) __attribute__((always_inline))  {
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      if (ok) *reinterpret_cast<uint4*>(pix + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    };
+    if constexpr (!POOL) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int y = yb + n;
+        const bool ok = y < p.H && x < p.W;
+        _Float16* pix = p.out + ((size_t)(b * p.H + y) * p.W + x) * p.cout + cb * 64;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const f16x_t& a = acc[m][n];
+            store_pair(pix, m, g, relu2(a[4 * g + 0], a[4 * g + 1]), relu2(a[4 * g + 2], a[4 * g + 3]),
+                       relu2(a[4 * g + 4], a[4 * g + 5]), relu2(a[4 * g + 6], a[4 * g + 7]), ok);
+          }
+      }
+    } else {
+      const int Ho = p.H >> 1, Wo = p.W >> 1;
+      const int yo = yb >> 1, xo = x >> 1;
+      const bool ok = !(x & 1) && yo < Ho && xo < Wo;
+      _Float16* pix = p.out + ((size_t)(b * Ho + yo) * Wo + xo) * p.cout + cb * 64;
+      auto pool1 = [&](int m, int r) __attribute__((always_inline))  -> float {  // max over the wave's two rows and 0 (v_max3), then over the column pair (dpp)
+        const float tt = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), 0.f);
+        const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tt), 0xB1, 0xF, 0xF, false));
+        return fmaxf(tt, nb);
+      };
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2)
+          store_pair(pix, m, g, pack2(pool1(m, 4 * g + 0), pool1(m, 4 * g + 1)), pack2(pool1(m, 4 * g + 2), pool1(m, 4 * g + 3)),
+                     pack2(pool1(m, 4 * g + 4), pool1(m, 4 * g + 5)), pack2(pool1(m, 4 * g + 6), pool1(m, 4 * g + 7)), ok);
+    }
+  };
+
+  // ---------------- schedule ----------------
+  // Half-step s: group (s & 1) runs the MFMAs of its item s >> 1, the other group moves data: the weight-ring half for the
+  // next pair of half-steps (chunk ((s >> 1) + 1) & 3, half s & 1), its next item's tile chunk into LDS, the prefetch of the
+  // one after.  Each group has its own straight-line loop over its tiles (4 chunks unrolled) instead of one loop with a role
+  // branch: the accumulators are then defined by chunk 0 and consumed by the epilogue inside one iteration - with the role
+  // branch they were loop-carried through a phi, which cost 96 register moves per item in the MFMA role.
+  const int T0 = (n_wg + 1) >> 1, T1 = n_wg >> 1;  // tiles of group 0 / 1 (T0 - T1 is 0 or 1)
+  unsigned long long* trow = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 6;
+  const bool tr_lane = SSHIP_PP_TRACE_BUILD && p.trace && gw == 0 && lane == 0;
+  unsigned long long t0 = 0, t1 = 0;
+  // SET: register set holding the item to stage; the prefetch goes to the other one.  Order: weight DMA first (longest latency,
+  // ~2 k clocks to land), then the prefetch loads, then the LDS writes of the staged item (their loads are two half-steps old
+  // and the oldest in the queue), and only then the wait for the DMA - most of its latency is behind the LDS writes by then.
+  auto data_role = [&](auto set_c, int dma_chunk, int dma_half, bool do_stage, bool do_prefetch, int pf_chunk, bool tr) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(SSHIP_PP_PRIO);
+    if (tr) t0 = __builtin_readcyclecounter();
+    if (dma_chunk >= 0) fill_weights(dma_chunk, dma_half);
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[0] = t1 - t0; t0 = t1; }
+    if (do_prefetch) prefetch_in(pf_chunk, std::integral_constant<int, SET ^ 1>{});
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[2] = t1 - t0; t0 = t1; }
+    if (do_stage) stage_in(set_c);
+    if (do_prefetch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // the weight DMA has landed; the six prefetch loads stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[1] = t1 - t0; t0 = t1; }
+    __syncthreads();
+    if (tr) trow[4] = __builtin_readcyclecounter() - t0;
+    if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  auto mfma_role = [&](auto chunk_c, bool tr) __attribute__((always_inline)) {
+    constexpr int chunk = decltype(chunk_c)::value;
+    if (tr) t0 = __builtin_readcyclecounter();
+    mfma_item(chunk_c);
+    if constexpr (chunk == Q_NCHUNK - 1) epilogue();
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[3] = t1 - t0; t0 = t1; }
+    __syncthreads();
+    if (tr) trow[5] = __builtin_readcyclecounter() - t0;
+  };
+  const std::integral_constant<int, 0> c0{}, setA{};
+  const std::integral_constant<int, 1> c1{}, setB{};
+  const std::integral_constant<int, 2> c2{};
+  const std::integral_constant<int, 3> c3{};
+  if ((grp ? T1 : T0) > 0) prefetch_in(0, setA);
+  __syncthreads();  // slot 0 and the bias are in LDS
+  if (grp == 0) {
+    data_role(setA, -1, 0, true, true, 1, false);  // half-step -1: item 0 into LDS, prefetch item 1
+#pragma unroll 1
+    for (int it = 0; it < T0; ++it) {
+      const bool more = it + 1 < T0, tr = tr_lane && it == 1;
+      mfma_role(c0, tr);
+      data_role(setB, 1, 1, true, true, 2, tr);
+      mfma_role(c1, false);
+      data_role(setA, 2, 1, true, true, 3, false);
+      mfma_role(c2, false);
+      data_role(setB, 3, 1, true, more, 0, false);
+      mfma_role(c3, false);
+      data_role(setA, 0, 1, more, more, 1, false);
+    }
+  } else {
+    __syncthreads();  // half-step -1: nothing to do for this group
+#pragma unroll 1
+    for (int it = 0; it < T1; ++it) {
+      const bool more = it + 1 < T1, tr = tr_lane && it == 1;
+      data_role(setA, 1, 0, true, true, 1, tr);
+      mfma_role(c0, tr);
+      data_role(setB, 2, 0, true, true, 2, false);
+      mfma_role(c1, false);
+      data_role(setA, 3, 0, true, true, 3, false);
+      mfma_role(c2, false);
+      data_role(setB, 0, 0, true, more, 0, false);
+      mfma_role(c3, false);
+    }
+    if (T0 > T1) {  // group 0 has one more tile: keep its weight ring filled and keep the barrier count
+#pragma unroll 1
+      for (int c = 0; c < Q_NCHUNK; ++c) {
+        data_role(setA, (c + 1) & 3, 0, false, false, 0, false);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+template <bool POOL>
+static hipError_t launch_pp128(const Pp128Args& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)(2 * Q_W_SLOT + 2 * Q_IN_HALFS) * 2 + 128 * 4;
+  static_assert(smem <= 163840, "LDS budget");
+  auto kern = conv3x3_pp128<POOL>;
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (attr_rc != hipSuccess) return attr_rc;
+  const int ncb = a.cout / 64;
+  const int ntiles = a.B * ((a.W + Q_TW - 1) / Q_TW) * ((a.H + Q_TH - 1) / Q_TH);
+  int gx = cu_count() / ncb;  // one persistent workgroup per CU
+  if (gx < 1) gx = 1;
+  if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;
+  if (gx < 1) gx = 1;
+  static const bool trace_on = SSHIP_PP_TRACE_BUILD && getenv("SSHIP_PP_TRACE") != nullptr;
+  static unsigned long long* tbuf = nullptr;
+  Pp128Args b = a;
+  if (trace_on) {
+    if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 2 * 6 * 8);
+    (void)hipMemsetAsync(tbuf, 0, 4096 * 2 * 6 * 8, s);
+    b.trace = tbuf;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, ncb), dim3(512), smem, s, b);
+  if (trace_on) {
+    std::vector<unsigned long long> h(4096 * 2 * 6);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum[6] = {0}; long cnt = 0;
+    for (int i = 0; i < gx * ncb * 2; ++i) {
+      if (!h[i * 6 + 3]) continue;
+      for (int k = 0; k < 6; ++k) sum[k] += (double)h[i * 6 + k];
+      ++cnt;
+    }
+    if (cnt) fprintf(stderr, "[pp128 trace cout=%d pool=%d] weight dma issue=%.0f stage+dma wait=%.0f prefetch issue=%.0f | mfma=%.0f | barrier wait after data=%.0f after mfma=%.0f (clk, %ld groups)\n",
+                     a.cout, (int)POOL, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, cnt);
+  }
+  return hipGetLastError();
+}
+
+// byte offsets inside the kernel are 32-bit (buffer addressing): inputs of 2 GiB and more stay on the 32-row-tile kernel
+bool sp_conv3x3_pp128_fits(int B, int H, int W) { return (size_t)B * H * W * 256 + (size_t)(W + 1) * 512 < 0x7f000000ull; }
+
+// w.w_q: packed by upload_conv_q (cout tile 64, chunk 32)
+hipError_t sp_conv3x3_pp128(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s) {
+  if (w.cin != 128 || !w.w_q || w.cout % 64 || !sp_conv3x3_pp128_fits(B, H, W)) return hipErrorInvalidValue;
+  Pp128Args a{};
+  a.in = in; a.wpack = w.w_q; a.bias = w.bias; a.out = out; a.B = B; a.H = H; a.W = W; a.cout = w.cout;
+  return pool ? launch_pp128<true>(a, s) : launch_pp128<false>(a, s);
+}
+
+}  // namespace sship
