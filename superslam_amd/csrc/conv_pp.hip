@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "igemm.h"
@@ -28,10 +29,6 @@
 // (incl. the fused conv1a+conv1b), everything for the 128-channel ones (build.py --variant -DSSHIP_PP_EPI=n to sweep)
 #ifndef SSHIP_PP_EPI
 #define SSHIP_PP_EPI -1
-#endif
-// staging geometry hoisted out of the tile loop: -1 = per-kernel default (128-input-channel layers only), 0 / 1 force
-#ifndef SSHIP_PP_HOIST
-#define SSHIP_PP_HOIST -1
 #endif
 // role tracing (SSHIP_PP_TRACE=1 at run time) is compiled in only on request: it costs registers in the fused kernel
 #ifndef SSHIP_PP_TRACE_BUILD
@@ -53,7 +50,6 @@ struct PpArgs {
   const float* bias;
   _Float16* out;
   int B, H, W, cout;
-  int dbg;  // ablation (SSHIP_PP_DBG): 1 skip staging, 2 skip epilogue, 4 skip MFMA loop, 8 skip prefetch
   unsigned long long* trace;  // SSHIP_PP_TRACE: [workgroup][group][4] clocks of half-steps 8..9: epilogue, stage, prefetch, mfma
 };
 
@@ -69,17 +65,19 @@ __device__ __forceinline__ int pp_lds(int row, int col, int unit) {
   return (row * P_TWH + col) * 64 + ((unit ^ ((col >> 1) & 7)) << 3);
 }
 
+struct PpWalk { int tx, ty, b; };  // wave-uniform tile coordinates of a group's tile stream (stride 2 tiles)
+
 template <int CIN, int CT, bool POOL, bool FUSE1A>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   constexpr int MT = CT / 32, NCHUNK = CIN / 64;
-  constexpr int HOIST_GEOMETRY = SSHIP_PP_HOIST < 0 ? (CIN == 128 ? 1 : 0) : SSHIP_PP_HOIST;
-  constexpr int EPI_MFMA = SSHIP_PP_EPI < 0 ? (CIN == 128 ? 2 : 0) : (SSHIP_PP_EPI > 2 * MT ? 2 * MT : SSHIP_PP_EPI);
+  constexpr int EPI_MFMA = SSHIP_PP_EPI < 0 ? (CIN == 128 ? 2 * MT : 0) : (SSHIP_PP_EPI > 2 * MT ? 2 * MT : SSHIP_PP_EPI);
+  constexpr int PIX_B = CIN * 2;  // bytes per input pixel
   static_assert(NCHUNK * 9 * 4 * MT * 512 == P_W_HALFS, "weights must fill exactly 72 KiB");
   static_assert(!FUSE1A || CIN == 64, "conv1a fusion feeds a 64-channel layer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   _Float16* s_w = reinterpret_cast<_Float16*>(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
-  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);  // wave-uniform role selector (keeps the role branch scalar)
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);  // wave-uniform role selector
   const int gw = wave & 3, gt = tid & 255;
   _Float16* my_in = s_w + P_W_HALFS + grp * P_IN_HALFS;
 
@@ -90,21 +88,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   const int t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
   const int n_wg = t_end - t_begin;
   if (n_wg <= 0) return;
-  // group g takes tiles t_begin + g, t_begin + g + 2, ...; a work item is (tile, 64-channel chunk)
-  const int nw0 = ((n_wg + 1) >> 1) * NCHUNK, nw1 = (n_wg >> 1) * NCHUNK;
-  const int NW = grp ? nw1 : nw0;
-  const int s_end = max(2 * nw0 - 1, 2 * nw1);  // last half-step in which some group still has an epilogue to write
+  // group g takes tiles t_begin + g, t_begin + g + 2, ...
+  const int T0 = (n_wg + 1) >> 1, T1 = n_wg >> 1, T_mine = grp ? T1 : T0;
 
   {  // weights: once per workgroup, all 512 threads
     const _Float16* wsrc = p.wpack + (size_t)cb * P_W_HALFS;
     for (int u = tid; u < P_W_HALFS / 8; u += 512)
       *reinterpret_cast<uint4*>(s_w + u * 8) = *reinterpret_cast<const uint4*>(wsrc + u * 8);
   }
-  // bias of this workgroup's CT channels lives in LDS (registers are the scarce resource here: acc 64 + prefetch 44 +
-  // fragment double buffers 32 per lane), read back as float4 in the epilogue
+  // bias of this workgroup's CT channels in LDS, one copy per N-tile: the accumulators start from it, each quad by its own
+  // ds_read_b128 (two copies so the compiler cannot merge the reads of the two N-tiles and then copy registers)
   float* s_bias = reinterpret_cast<float*>(s_w + P_W_HALFS + 2 * P_IN_HALFS);
-  if (tid < CT) s_bias[tid] = p.bias[cb * CT + tid];
-  if constexpr (FUSE1A) { if (tid >= 64 && tid < 128) s_bias[tid] = p.b1a[tid - 64]; }  // conv1a bias at s_bias[64..127]
+  if (tid < 2 * CT) s_bias[tid] = p.bias[cb * CT + (tid % CT)];
   // fragment-read offsets: B fragment of (row n + ky, col j + kx), k-step ks -> unit (2 ks + hh) ^ ((j + kx) >> 1 & 7)
   int boff[3][4];
 #pragma unroll
@@ -112,70 +107,70 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) boff[kx][ks] = (j + kx) * 64 + (((2 * ks + hh) ^ (((j + kx) >> 1) & 7)) << 3);
 
-  auto tile_of = [&](int item) { return t_begin + grp + 2 * (item / NCHUNK); };
-  auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
-    const int tx = t % tiles_x;
+  auto walk_init = [&](int t) __attribute__((always_inline)) {
+    PpWalk w;
+    w.tx = t % tiles_x;
     const int r = t / tiles_x;
-    x0 = tx * P_TW; y0 = (r % tiles_y) * P_TH; b = r / tiles_y;
+    w.ty = r % tiles_y; w.b = r / tiles_y;
+    return w;
   };
-
-  // ---------------- staging (plain variant): global -> registers (prefetch) -> LDS ----------------
-  uint4 rin[FUSE1A ? 1 : P_IN_IT];
-  // Edge tiles load from a clamped (always valid) address and are masked when the tile is WRITTEN to LDS one step
-  // later: selecting zero here would need the data, i.e. a vmcnt(0) in front of every one of the 11 loads (traced:
-  // 30k+ clocks for an edge tile's prefetch against ~1k for an interior one).
-  auto prefetch_in = [&](int item) {
-    if constexpr (!FUSE1A) {
-      int b, y0, x0;
-      tile_coords(tile_of(item), b, y0, x0);
-      const int chunk = item % NCHUNK;
-      int gtv = gt;
-      // CIN = 64 (MT = 2, ~250 VGPRs): opaque, keeps the per-iteration geometry from being hoisted into ~50 live VGPRs.
-      // CIN = 128 (MT = 1, ~165 VGPRs) has the registers: the offsets are computed once per launch instead of ~330
-      // integer instructions per half-step in the (critical) data-movement role.
-      if (HOIST_GEOMETRY == 0) asm volatile("" : "+v"(gtv));
-      const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
-      if (interior) {
-        const _Float16* base = p.in + ((size_t)(b * p.H + (y0 - 1)) * p.W + (x0 - 1)) * CIN + chunk * 64;
-#pragma unroll
-        for (int i = 0; i < P_IN_IT; ++i) {
-          const int u = gtv + i * 256;
-          const int pix = u >> 3, part = u & 7;
-          const int py = pix / P_TWH, px = pix - py * P_TWH;
-          if (i < P_IN_IT - 1 || u < P_IN_UNITS) rin[i] = *reinterpret_cast<const uint4*>(base + (py * p.W + px) * CIN + part * 8);
-        }
-      } else {
-        const _Float16* img = p.in + (size_t)b * p.H * p.W * CIN + chunk * 64;
-#pragma unroll
-        for (int i = 0; i < P_IN_IT; ++i) {
-          const int u = min(gtv + i * 256, P_IN_UNITS - 1);
-          const int pix = u >> 3, part = u & 7;
-          const int py = pix / P_TWH, px = pix - py * P_TWH;
-          const int cy = min(max(y0 - 1 + py, 0), p.H - 1), cx = min(max(x0 - 1 + px, 0), p.W - 1);
-          rin[i] = *reinterpret_cast<const uint4*>(img + ((size_t)cy * p.W + cx) * CIN + part * 8);
-        }
-      }
+  auto walk_next = [&](PpWalk& w) __attribute__((always_inline)) {  // two tiles further along the (b, ty, tx) raster
+    w.tx += 2;
+    while (w.tx >= tiles_x) {
+      w.tx -= tiles_x;
+      if (++w.ty == tiles_y) { w.ty = 0; ++w.b; }
     }
   };
-  auto stage_in = [&](int item) {
+  PpWalk pw = walk_init(t_begin + grp), sw = pw, ew = pw;  // tile of the next prefetch / staging / epilogue
+
+  // ---------------- staging (plain variant): global -> registers (prefetch) -> LDS ----------------
+  // The data-movement role shares its SIMD with a wave that has 144 MFMAs queued and pays ~10 clocks per VALU instruction
+  // (profiles/r02_pp_role_trace.txt), so the addressing is affine: thread t of the group owns 16-byte unit t of the 272
+  // units of halo row i (i = 0..9) - one VGPR offset plus a scalar per-row offset for the ten buffer loads, one LDS address
+  // plus an immediate for the ten ds_write_b128; the 16 left-over units per row are an eleventh load of threads 0..159.
+  // Out-of-image halo pixels get their voffset pushed out of the buffer's range: the load returns zeros, nothing is masked
+  // afterwards.  The buffer is rebuilt per tile on the image (base one row and one pixel before it), offsets stay 32-bit.
+  typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+  constexpr unsigned P_OOB = 0xfffffff0u;
+  constexpr int P_ROW_UNITS = P_TWH * 8;  // 272
+  u4_t rin[FUSE1A ? 1 : 11];
+  const int m_px = gt >> 3, m_part = gt & 7;                                   // main part: unit gt of a halo row
+  const int r_row = gt >> 4, r_px = 32 + ((gt & 15) >> 3), r_part = gt & 7;    // remainder: units 256..271 of row gt >> 4
+  const bool r_on = gt < 160;
+  const unsigned voff_main = (unsigned)(m_px * PIX_B + m_part * 16);
+  const unsigned voff_rem = r_on ? (unsigned)((r_row * p.W + r_px) * PIX_B + r_part * 16) : P_OOB;
+  _Float16* lds_main = my_in + pp_lds(0, m_px, m_part);  // + i rows for halo row i
+  _Float16* lds_rem = my_in + pp_lds(r_on ? r_row : 0, r_px, r_part);
+  const unsigned row_bytes = (unsigned)(p.W * PIX_B);
+  auto prefetch_in = [&](int chunk) __attribute__((always_inline)) {
     if constexpr (!FUSE1A) {
-      int b, y0, x0;
-      tile_coords(tile_of(item), b, y0, x0);
+      const int y0 = pw.ty * P_TH, x0 = pw.tx * P_TW;
+      const char* img = reinterpret_cast<const char*>(p.in) + (size_t)pw.b * p.H * p.W * PIX_B - (size_t)(p.W + 1) * PIX_B;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (int)0x7ffffff0, 0x00020000);
+      const unsigned soff = (unsigned)(y0 * p.W + x0) * (unsigned)PIX_B + (unsigned)chunk * 128u;
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
-      int gtv = gt;
-      if (HOIST_GEOMETRY == 0) asm volatile("" : "+v"(gtv));
+      if (interior) {
 #pragma unroll
-      for (int i = 0; i < P_IN_IT; ++i) {
-        const int u = gtv + i * 256;
-        const int pix = u >> 3, part = u & 7;
-        const int py = pix / P_TWH, px = pix - py * P_TWH;
-        uint4 v = rin[i];
-        if (!interior) {  // zero padding outside the image (uniform branch: only edge tiles pay for the index math)
-          const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-          if (!(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)) v = make_uint4(0, 0, 0, 0);
-        }
-        if (i < P_IN_IT - 1 || u < P_IN_UNITS) *reinterpret_cast<uint4*>(my_in + pp_lds(py, px, part)) = v;
+        for (int i = 0; i < 10; ++i) rin[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_main, soff + i * row_bytes, 0);
+        rin[10] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_rem, soff, 0);
+      } else {
+        // halo row r is inside the image for rlo <= r <= rhi, halo column c for clo <= c <= chi
+        const int rlo = y0 == 0 ? 1 : 0, rhi = min(P_THH - 1, p.H - y0), clo = x0 == 0 ? 1 : 0, chi = min(P_TWH - 1, p.W - x0);
+        const unsigned vm = (m_px >= clo && m_px <= chi) ? voff_main : P_OOB;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+          rin[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (i >= rlo && i <= rhi) ? vm : P_OOB, soff + i * row_bytes, 0);
+        const bool r_ok = r_px >= clo && r_px <= chi && r_row >= rlo && r_row <= rhi;
+        rin[10] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, r_ok ? voff_rem : P_OOB, soff, 0);
       }
+      if (chunk == NCHUNK - 1) walk_next(pw);
+    }
+  };
+  auto stage_in = [&]() __attribute__((always_inline)) {
+    if constexpr (!FUSE1A) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) *reinterpret_cast<u4_t*>(lds_main + i * (P_TWH * 64)) = rin[i];
+      if (r_on) *reinterpret_cast<u4_t*>(lds_rem) = rin[10];
     }
   };
   // ---------------- staging (FUSE1A): u8 pixels -> registers (prefetch) -> conv1a MFMA -> LDS ----------------
@@ -195,11 +190,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       c1_lds[k] = ((py * P_TWH + px) * 64 + hh * 4) | (((px >> 1) & 7) << 24);  // half offset | swizzle term
     }
   }
-  auto prefetch_u8 = [&](int item) {
+  auto prefetch_u8 = [&]() __attribute__((always_inline)) {
     if constexpr (FUSE1A) {
-      int b, y0, x0;
-      tile_coords(tile_of(item), b, y0, x0);
-      const uint8_t* im = p.img + (size_t)b * p.H * p.W;
+      const int y0 = pw.ty * P_TH, x0 = pw.tx * P_TW;
+      const uint8_t* im = p.img + (size_t)pw.b * p.H * p.W;
+      walk_next(pw);
       // interior: the whole 12 x 36 patch (+3 bytes of dword over-read) lies inside the image -> three unaligned
       // dword loads per pixel, no clamping (24 clamped byte loads per lane made this the longest part of the step)
       const bool interior = y0 >= 2 && y0 + P_TH + 2 <= p.H && x0 >= 2 && x0 + P_TW + 2 + 3 <= p.W;
@@ -235,13 +230,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     a1a0 = *reinterpret_cast<const h8_t*>(p.w1a + lane * 8);
     a1a1 = *reinterpret_cast<const h8_t*>(p.w1a + 512 + lane * 8);
   }
-  bool tr_stage = false;  // set by the half-step loop for the traced half-steps (SSHIP_PP_TRACE_BUILD)
-  auto stage_conv1a = [&](int item) {
+  unsigned long long* trow = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10;
+  auto stage_conv1a = [&](bool tr_stage) __attribute__((always_inline)) {
     if constexpr (FUSE1A) {
       unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
       if (SSHIP_PP_TRACE_BUILD && tr_stage) ts0 = __builtin_readcyclecounter();
-      int b, y0, x0;
-      tile_coords(tile_of(item), b, y0, x0);
+      const int y0 = sw.ty * P_TH, x0 = sw.tx * P_TW;
+      walk_next(sw);
       const bool interior = y0 >= 1 && y0 + P_TH + 1 <= p.H && x0 >= 1 && x0 + P_TW + 1 <= p.W;
       const bool patch_interior = y0 >= 2 && y0 + P_TH + 2 <= p.H && x0 >= 2 && x0 + P_TW + 2 + 3 <= p.W;  // as in prefetch_u8
       // three passes over this wave's (up to) 3 N-tiles so the six conv1a MFMAs issue back to back and their latency
@@ -278,14 +273,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         bf[k][7] = hh ? (_Float16)0.f : t[2][1];
       }
       if (SSHIP_PP_TRACE_BUILD && tr_stage) ts1 = __builtin_readcyclecounter();
+      const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f16x_t d0[NT_W], d1[NT_W];
 #pragma unroll
       for (int k = 0; k < NT_W; ++k) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { d0[k][r] = 0.f; d1[k][r] = 0.f; }
         if (gw + 4 * k >= P_NT1A) continue;  // wave-uniform
-        d0[k] = mfma32(a1a0, bf[k], d0[k]);
-        d1[k] = mfma32(a1a1, bf[k], d1[k]);
+        d0[k] = mfma32(a1a0, bf[k], zero16);  // C = inline constant 0: no accumulator initialisation
+        d1[k] = mfma32(a1a1, bf[k], zero16);
       }
       if (SSHIP_PP_TRACE_BUILD && tr_stage) ts2 = __builtin_readcyclecounter();
 #pragma unroll
@@ -297,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
             const int gy = y0 - 1 + (c1_pypx[k] >> 16), gx = x0 - 1 + (c1_pypx[k] & 0xffff);
             inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
           }
-          const int base = c1_lds[k] & 0xffffff, sw = c1_lds[k] >> 24;
+          const int base = c1_lds[k] & 0xffffff, swz = c1_lds[k] >> 24;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             // ReLU after the fp16 rounding, two values per instruction (v_pk_max_f16): rounding is monotone and keeps the
@@ -306,37 +300,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
             h4_t o0 = __builtin_elementwise_max(to_h4(d0[k][4 * g], d0[k][4 * g + 1], d0[k][4 * g + 2], d0[k][4 * g + 3]), z4);
             h4_t o1 = __builtin_elementwise_max(to_h4(d1[k][4 * g], d1[k][4 * g + 1], d1[k][4 * g + 2], d1[k][4 * g + 3]), z4);
             if (!interior && !inside) { o0 = z4; o1 = z4; }  // `interior` is uniform: inner tiles skip the selects
-            const int u0 = (g ^ sw) << 3;  // channels 4 hh + 8 g .. (+3): unit g; M-tile 1: unit 4 + g
+            const int u0 = (g ^ swz) << 3;  // channels 4 hh + 8 g .. (+3): unit g; M-tile 1: unit 4 + g
             *reinterpret_cast<h4_t*>(my_in + base + u0) = o0;
             *reinterpret_cast<h4_t*>(my_in + base + (u0 ^ 32)) = o1;
           }
         }
       }
-      if (SSHIP_PP_TRACE_BUILD && tr_stage) {
-        unsigned long long* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10;
-        o[6] = ts1 - ts0; o[7] = ts2 - ts1; o[8] = __builtin_readcyclecounter() - ts2;
-      }
+      if (SSHIP_PP_TRACE_BUILD && tr_stage) { trow[6] = ts1 - ts0; trow[7] = ts2 - ts1; trow[8] = __builtin_readcyclecounter() - ts2; }
     }
   };
 
   f16x_t acc[MT][2];
-  // ---------------- MFMA half-step: 36 k-steps of one 64-channel chunk, fragments double-buffered ----------------
-  auto mfma_item = [&](int item) {
-    const int chunk = item % NCHUNK;
-    if (chunk == 0) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    }
+  // ---------------- MFMA half-step: 36 k-steps of one 64-channel chunk, fragments triple-buffered ----------------
+  // Chunk 0 starts the accumulators from the bias (row 8 g + 4 hh + e of M-tile m is register 4 g + e: one ds_read_b128 per
+  // quad, straight into the accumulator registers); a tile's accumulators are defined and consumed inside one loop iteration.
+  auto mfma_item = [&](auto chunk_c) __attribute__((always_inline)) {
+    constexpr int chunk = decltype(chunk_c)::value;
     const _Float16* wc = s_w + chunk * (9 * 4 * MT * 512) + lane * 8;
     const _Float16* ib = my_in + (gw * 2) * P_TWH * 64;
     // one wave per SIMD feeds the matrix pipe here, so LDS latency must be covered by this wave alone: fragments are
     // triple-buffered, the ds_reads of k-step i+2 are issued (and pinned) before the MFMAs of k-step i.
     h8_t fa[3][MT], fb[3][2];
-    auto load_frags = [&](int idx, int buf) {
+    auto load_frags = [&](int idx, int buf) __attribute__((always_inline)) {
       const int tap = idx >> 2, ks = idx & 3, ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
       for (int m = 0; m < MT; ++m) fa[buf][m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
@@ -345,6 +330,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     };
     load_frags(0, 0);
     load_frags(1, 1);
+    if constexpr (chunk == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(s_bias + n * CT + m * 32 + hh * 4 + g * 8);
+            acc[m][n][4 * g + 0] = b4.x; acc[m][n][4 * g + 1] = b4.y; acc[m][n][4 * g + 2] = b4.z; acc[m][n][4 * g + 3] = b4.w;
+          }
+    }
 #pragma unroll
     for (int idx = 0; idx < 36; ++idx) {
       if (idx + 2 < 36) load_frags(idx + 2, (idx + 2) % 3);
@@ -356,120 +352,128 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // ---------------- epilogue: bias + ReLU (+ 2x2 max-pool) -> fp16 channels-last, 16-byte stores ----------------
-  // units u = 2 m + g / 2 (one 16-byte store per pixel each); [u_lo, u_hi) selects which part of the tile this call writes
-  auto epilogue = [&](int item, int u_lo, int u_hi) {
-    int b, y0, x0;
-    tile_coords(tile_of(item), b, y0, x0);
+  // ---------------- epilogue: ReLU (+ 2x2 max-pool) -> fp16 channels-last, 16-byte stores; the bias is already in ----------------
+  // units u = 2 m + g / 2 (one 16-byte store per pixel each); [u_lo, u_hi) selects which part of the tile this call writes;
+  // the call with u_hi == 2 MT advances the epilogue walker
+  auto epilogue = [&](int u_lo, int u_hi) __attribute__((always_inline)) {
+    const int y0 = ew.ty * P_TH, x0 = ew.tx * P_TW, b = ew.b;
+    if (u_hi == 2 * MT) walk_next(ew);
     const int yb = y0 + gw * 2, x = x0 + j;
-    auto pack2 = [](float lo, float hi) -> unsigned {
+    const h2_t z2 = {(_Float16)0.f, (_Float16)0.f};
+    auto relu2 = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {  // two values -> packed fp16, ReLU on the pair
+      h2_t v = {(_Float16)lo, (_Float16)hi};
+      v = __builtin_elementwise_max(v, z2);
+      return *reinterpret_cast<const unsigned*>(&v);
+    };
+    auto pack2 = [](float lo, float hi) __attribute__((always_inline)) -> unsigned {
       const h2_t v = {(_Float16)lo, (_Float16)hi};
       return *reinterpret_cast<const unsigned*>(&v);
     };
-    auto store_pair = [&](_Float16* pix, int m, int g, const float (&q0)[4], const float (&q1)[4], bool ok) {
-      const unsigned a0 = pack2(q0[0], q0[1]), a1 = pack2(q0[2], q0[3]);
-      const unsigned b0 = pack2(q1[0], q1[1]), b1 = pack2(q1[2], q1[3]);
+    // lanes hh = 0 / 1 hold channels 4 hh .. + 3 of an 8-channel unit: permlane32_swap pairs them into one 16-byte store each
+    auto store_pair = [&](_Float16* pix, int m, int g, unsigned a0, unsigned a1, unsigned b0, unsigned b1, bool ok) __attribute__((always_inline)) {
       const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
       const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-      if (ok) *reinterpret_cast<uint4*>(pix + cb * CT + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      if (ok) *reinterpret_cast<uint4*>(pix + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     };
     if constexpr (!POOL) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const int y = yb + n;
         const bool ok = y < p.H && x < p.W;
-        _Float16* pix = p.out + ((size_t)(b * p.H + y) * p.W + x) * p.cout;
+        _Float16* pix = p.out + ((size_t)(b * p.H + y) * p.W + x) * p.cout + cb * CT;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int g = 0; g < 4; g += 2) {
             if (2 * m + g / 2 < u_lo || 2 * m + g / 2 >= u_hi) continue;
-            float q0[4], q1[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              q0[e] = fmaxf(acc[m][n][4 * g + e] + s_bias[m * 32 + hh * 4 + g * 8 + e], 0.f);
-              q1[e] = fmaxf(acc[m][n][4 * (g + 1) + e] + s_bias[m * 32 + hh * 4 + (g + 1) * 8 + e], 0.f);
-            }
-            store_pair(pix, m, g, q0, q1, ok);
+            const f16x_t& a = acc[m][n];
+            store_pair(pix, m, g, relu2(a[4 * g + 0], a[4 * g + 1]), relu2(a[4 * g + 2], a[4 * g + 3]),
+                       relu2(a[4 * g + 4], a[4 * g + 5]), relu2(a[4 * g + 6], a[4 * g + 7]), ok);
           }
       }
     } else {
       const int Ho = p.H >> 1, Wo = p.W >> 1;
       const int yo = yb >> 1, xo = x >> 1;
       const bool ok = !(x & 1) && yo < Ho && xo < Wo;
-      _Float16* pix = p.out + ((size_t)(b * Ho + yo) * Wo + xo) * p.cout;
-      auto pool4 = [&](int m, int g, float (&q)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float tt = fmaxf(acc[m][0][4 * g + e], acc[m][1][4 * g + e]);
-          const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tt), 0xB1, 0xF, 0xF, false));
-          q[e] = fmaxf(fmaxf(tt, nb) + s_bias[m * 32 + hh * 4 + g * 8 + e], 0.f);
-        }
+      _Float16* pix = p.out + ((size_t)(b * Ho + yo) * Wo + xo) * p.cout + cb * CT;
+      auto pool1 = [&](int m, int r) __attribute__((always_inline)) -> float {  // max over the wave's two rows and 0 (v_max3), then the column pair (dpp)
+        const float tt = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), 0.f);
+        const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tt), 0xB1, 0xF, 0xF, false));
+        return fmaxf(tt, nb);
       };
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
           if (2 * m + g / 2 < u_lo || 2 * m + g / 2 >= u_hi) continue;
-          float q0[4], q1[4];
-          pool4(m, g, q0);
-          pool4(m, g + 1, q1);
-          store_pair(pix, m, g, q0, q1, ok);
+          store_pair(pix, m, g, pack2(pool1(m, 4 * g + 0), pool1(m, 4 * g + 1)), pack2(pool1(m, 4 * g + 2), pool1(m, 4 * g + 3)),
+                     pack2(pool1(m, 4 * g + 4), pool1(m, 4 * g + 5)), pack2(pool1(m, 4 * g + 6), pool1(m, 4 * g + 7)), ok);
         }
     }
   };
 
-  // item w of group g: staged in half-step 2w + g - 1, MFMA in 2w + g, epilogue (after its last chunk) in 2w + g + 1
-  if (NW > 0) { if constexpr (FUSE1A) prefetch_u8(0); else prefetch_in(0); }
-#pragma unroll 1
-  for (int s = -1; s <= s_end; ++s) {
-    const bool tr = SSHIP_PP_TRACE_BUILD && p.trace && (s == 8 || s == 9) && gw == 0 && lane == 0;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  // ---------------- schedule ----------------
+  // Half-step s: group (s & 1) runs the MFMAs of its item (tile, chunk) s >> 1; the other group - on the same SIMDs - writes
+  // the epilogue of the tile it just finished, stages its next item into LDS and issues the prefetch for the one after.
+  // Both groups run the SAME straight-line loop (MFMA half-step, barrier, data half-step, barrier), group 1 one barrier
+  // behind group 0.  There is no role branch inside the loop: with one, the accumulators were loop-carried through a phi
+  // and the compiler moved all 64 of them to other registers and back around every MFMA half-step.
+  const bool tr_lane = SSHIP_PP_TRACE_BUILD && p.trace && gw == 0 && lane == 0;
+  unsigned long long t0 = 0, t1 = 0;
+  // data half-step after MFMA item (it, chunk): epilogue if that was the tile's last chunk; stage item + 1; prefetch item + 2
+  auto data_role = [&](bool do_epi, bool do_stage, bool do_prefetch, int pf_chunk, bool tr) __attribute__((always_inline)) {
+    if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(SSHIP_PP_PRIO);
     if (tr) t0 = __builtin_readcyclecounter();
-    tr_stage = tr;
-    if (((s + 1) & 1) == grp) {
-      // ---- data-movement role: epilogue of the item whose MFMA just finished, stage the next item, prefetch ----
-      // Static priority for the role (SSHIP_PP_PRIO, default on): this wave shares its SIMD with a wave that has 72-144 MFMAs ready
-      // back to back; at equal priority the older wave wins arbitration, and this role's few instructions (conv1a's six MFMAs, the
-      // LDS writes, the prefetch loads) queue behind that stream - the role trace had `stage` at 4.8 k clocks for ~1 k of work.
-      if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(SSHIP_PP_PRIO);
-      const int w_done = (s - 1 - grp) >> 1;  // item whose MFMA ran in half-step s - 1
-      if (s - 1 - grp >= 0 && w_done < NW && (w_done % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w_done, EPI_MFMA, 2 * MT);
-      if (tr) t1 = __builtin_readcyclecounter();
-      const int w_next = (s + 1 - grp) >> 1;  // item whose MFMA runs in half-step s + 1
-      if (w_next < NW) {
-        if (!(p.dbg & 1)) { if constexpr (FUSE1A) stage_conv1a(w_next); else stage_in(w_next); }
-        if (tr) t2 = __builtin_readcyclecounter();
-        if (w_next + 1 < NW && !(p.dbg & 8)) { if constexpr (FUSE1A) prefetch_u8(w_next + 1); else prefetch_in(w_next + 1); }
-      }
-      if (tr) {
-        t3 = __builtin_readcyclecounter();
-        unsigned long long* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10;
-        o[0] = t1 - t0; o[1] = t2 > t1 ? t2 - t1 : 0; o[2] = t2 ? t3 - t2 : 0;
-      }
-    } else {
-      if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(0);
-      const int w = (s - grp) >> 1;
-      if (s - grp >= 0 && w < NW && !(p.dbg & 4)) {
-        mfma_item(w);
-        // the first EPI_MFMA store units are written by the MFMA group itself right after its loop: the data-movement
-        // half-step (epilogue + staging + prefetch) is the longer of the two roles, this group would only wait for it
-        if (EPI_MFMA > 0 && (w % NCHUNK) == NCHUNK - 1 && !(p.dbg & 2)) epilogue(w, 0, EPI_MFMA);
-      }
-      if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10 + 3] = __builtin_readcyclecounter() - t0;
-    }
-    if (tr) t1 = __builtin_readcyclecounter();
+    if (do_epi && EPI_MFMA < 2 * MT) epilogue(EPI_MFMA, 2 * MT);
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[0] = t1 - t0; t0 = t1; }
+    if (do_stage) { if constexpr (FUSE1A) stage_conv1a(tr); else stage_in(); }
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[1] = t1 - t0; t0 = t1; }
+    if (do_prefetch) { if constexpr (FUSE1A) prefetch_u8(); else prefetch_in(pf_chunk); }
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[2] = t1 - t0; t0 = t1; }
     __syncthreads();
-    if (tr) p.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 10 + 4 + (((s + 1) & 1) == grp ? 0 : 1)] = __builtin_readcyclecounter() - t1;
+    if (tr) trow[4] = __builtin_readcyclecounter() - t0;
+    if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  auto mfma_role = [&](auto chunk_c, bool tr) __attribute__((always_inline)) {
+    constexpr int chunk = decltype(chunk_c)::value;
+    if (tr) t0 = __builtin_readcyclecounter();
+    mfma_item(chunk_c);
+    // the first EPI_MFMA store units are written by the MFMA group itself right after its loop
+    if constexpr (chunk == NCHUNK - 1 && EPI_MFMA > 0) epilogue(0, EPI_MFMA);
+    if (tr) { t1 = __builtin_readcyclecounter(); trow[3] = t1 - t0; t0 = t1; }
+    __syncthreads();
+    if (tr) trow[5] = __builtin_readcyclecounter() - t0;
+  };
+  const std::integral_constant<int, 0> c0{};
+  const std::integral_constant<int, NCHUNK - 1> c_last{};
+  // barriers per group: (grp) + 1 + 2 NCHUNK T_mine; both groups must reach the larger count
+  const int nbar_mine = grp + 1 + 2 * NCHUNK * T_mine, nbar_all = max(1 + 2 * NCHUNK * T0, 2 + 2 * NCHUNK * T1);
+  if (T_mine > 0) { if constexpr (FUSE1A) prefetch_u8(); else prefetch_in(0); }
+  __syncthreads();  // weights and bias are in LDS
+  if (grp == 1) __syncthreads();  // group 1 runs one half-step behind group 0
+  // first data half-step: item 0 into LDS, prefetch item 1
+  data_role(false, T_mine > 0, NCHUNK > 1 ? T_mine > 0 : T_mine > 1, NCHUNK > 1 ? 1 : 0, false);
+#pragma unroll 1
+  for (int it = 0; it < T_mine; ++it) {
+    const bool more = it + 1 < T_mine, tr = tr_lane && it == 2;
+    if constexpr (NCHUNK == 1) {
+      mfma_role(c0, tr);
+      data_role(true, more, it + 2 < T_mine, 0, tr);
+    } else {
+      mfma_role(c0, tr);
+      data_role(false, true, more, 0, tr);          // stage chunk 1 of this tile, prefetch chunk 0 of the next
+      mfma_role(c_last, false);
+      data_role(true, more, more, 1, false);        // epilogue; stage chunk 0 of the next tile, prefetch its chunk 1
+    }
   }
+#pragma unroll 1
+  for (int k = nbar_mine; k < nbar_all; ++k) __syncthreads();
 }
 
 template <int CIN, int CT, bool POOL, bool FUSE1A>
 static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
   PpArgs a = a_in;
-  static const int dbg = getenv("SSHIP_PP_DBG") ? atoi(getenv("SSHIP_PP_DBG")) : 0;
-  a.dbg = dbg;
-  constexpr size_t smem = (size_t)(2 * P_IN_HALFS + P_W_HALFS) * 2 + 128 * 4;
+  constexpr size_t smem = (size_t)(2 * P_IN_HALFS + P_W_HALFS) * 2 + 128 * 4;  // + bias [2][CT]
   static_assert(smem <= 163840, "LDS budget");
   auto kern = conv3x3_pp<CIN, CT, POOL, FUSE1A>;
   // thread-safe one-time opt-in to > 64 KiB of dynamic LDS (C++11 magic static; handles may be created on any thread)

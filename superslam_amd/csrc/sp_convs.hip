@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512) void k_desc_head_gather(const _Float16* __rest
 // normalisations above without leaving the CU.  600 keypoints of 8084 cells at KITTI size: 13x less convDa work
 // (it was the second most expensive head layer), and neither the 256-channel convDa map nor the descriptor grid is
 // written to HBM.  Arithmetic per output is the dense kernel's: same fp16 operands, same k order (64-channel chunk,
-// tap, k-step) into an fp32 accumulator, bias, ReLU, fp16.  reference: convert_superpoint_to_onnx.py:61-64,88-89.
+// tap, k-step) into an fp32 accumulator that starts at the bias, ReLU, fp16.  reference: convert_superpoint_to_onnx.py:61-64,88-89.
 // A workgroup (8 waves) owns 64 keypoints of one image; wave w owns output channels [32w, 32w+32) of both layers and
 // streams its 72 KiB of convDa fragments from L2 (packed exactly as the dense conv kernels read them, ct = 32).
 // ---------------------------------------------------------------------------------------------------
@@ -163,11 +163,13 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
     s_cell[tid] = i0 + tid < n ? (cell_h[(size_t)b * max_kp + i0 + tid] << 16) | cell_w[(size_t)b * max_kp + i0 + tid] : -1;
   const _Float16* img = a4b + (size_t)b * Hc * Wc * 128;
   // ---- convDa at the keypoints ----
-  f16x_t acc[2];
+  f16x_t acc[2];  // start from the bias, as the dense ping-pong kernel does (conv_pp.hip: same fp32 summation order)
 #pragma unroll
-  for (int nn = 0; nn < 2; ++nn)
+  for (int g = 0; g < 4; ++g) {
+    const float4 bv = *reinterpret_cast<const float4*>(bda + wave * 32 + hh * 4 + g * 8);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nn][r] = 0.f;
+    for (int nn = 0; nn < 2; ++nn) { acc[nn][4 * g] = bv.x; acc[nn][4 * g + 1] = bv.y; acc[nn][4 * g + 2] = bv.z; acc[nn][4 * g + 3] = bv.w; }
+  }
   const _Float16* wa = wda + (size_t)wave * (72 * 512) + lane * 8;  // [cb = wave][chunk][tap][kstep][lane][8]
   h8_t fa[2][12];  // two groups of 12 fragments (one kernel row: 3 taps x 4 k-steps) in flight
 #pragma unroll
@@ -214,12 +216,10 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
   }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const float4 bv = *reinterpret_cast<const float4*>(bda + wave * 32 + hh * 4 + g * 8);
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn)
       *reinterpret_cast<h4_t*>(s_x + (nn * 32 + j) * kDhLd + wave * 32 + hh * 4 + g * 8) =
-          to_h4(fmaxf(acc[nn][4 * g] + bv.x, 0.f), fmaxf(acc[nn][4 * g + 1] + bv.y, 0.f),
-                fmaxf(acc[nn][4 * g + 2] + bv.z, 0.f), fmaxf(acc[nn][4 * g + 3] + bv.w, 0.f));
+          to_h4(fmaxf(acc[nn][4 * g], 0.f), fmaxf(acc[nn][4 * g + 1], 0.f), fmaxf(acc[nn][4 * g + 2], 0.f), fmaxf(acc[nn][4 * g + 3], 0.f));
   }
   __syncthreads();
   // ---- convDb + F.normalize + gather renormalisation (as k_desc_head_gather) ----
