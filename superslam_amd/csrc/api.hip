@@ -1,6 +1,7 @@
 // C ABI of libsuperslam_hip.so (include/sship.h): weights, workspaces, streams and the launch sequences of
 // the SuperPoint extractor, the LightGlue matcher and the fused front-end step.  gfx950 only; there is no CPU
 // fallback anywhere in this library - without a GPU every entry point fails with SSHIP_ERR_NO_DEVICE.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -560,7 +561,7 @@ struct sship_sp {
   float* w1a = nullptr;  // [9][64] tap-major fp32 (fp16-rounded values)  (stand-alone conv1a kernel)
   float* b1a = nullptr;
   _Float16* w1a_frag = nullptr;   // conv1a as MFMA A fragments [2][64][8] (K = 9 taps zero-padded to 16)
-  _Float16* w1a_fragb = nullptr;  // same + the bias split into fp16 hi/lo parts in K slots 9 and 10 (ping-pong kernel)
+  _Float16* w1a_fragb = nullptr;  // ping-pong kernel: taps 0..4 | taps 5..8 + the bias split into fp16 hi/lo parts (see sship_sp_create)
   ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, cPa, cPb, cDa, cDb;
   ConvW cDb32;  // convDb packed in 32-row blocks (one per wave of k_desc_head_gather)
   sship_pool* pool = nullptr;
@@ -754,12 +755,21 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
         }
     SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp->w1a_frag), fr.size() * sizeof(_Float16)));
     SSHIP_HIP_CHECK(hipMemcpy(sp->w1a_frag, fr.data(), fr.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    // ping-pong kernel (conv_pp.hip, stage_conv1a): balanced K layout - lanes hh = 0 hold taps 0..4 in slots 0..4, lanes hh = 1
+    // taps 5..8 in slots 0..3 and the bias, split into fp16 hi / lo parts, in slots 4 and 5 (their B elements are 1.0)
+    std::fill(fr.begin(), fr.end(), (_Float16)0.f);
     for (int mt = 0; mt < 2; ++mt)
-      for (int lane = 32; lane < 64; ++lane) {  // hh = 1 lanes hold k = 8 .. 15: e = 1 -> k = 9 (hi), e = 2 -> k = 10 (lo)
-        const int co = mt * 32 + (lane & 31);
-        const _Float16 hi = (_Float16)b->data[co];
-        fr[(mt * 64 + lane) * 8 + 1] = hi;
-        fr[(mt * 64 + lane) * 8 + 2] = (_Float16)(b->data[co] - (float)hi);
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = mt * 32 + (lane & 31), hh = lane >> 5;
+        _Float16* f = &fr[(mt * 64 + lane) * 8];
+        if (hh == 0) {
+          for (int e = 0; e < 5; ++e) f[e] = (_Float16)w->data[co * 9 + e];
+        } else {
+          for (int e = 0; e < 4; ++e) f[e] = (_Float16)w->data[co * 9 + 5 + e];
+          const _Float16 hi = (_Float16)b->data[co];
+          f[4] = hi;
+          f[5] = (_Float16)(b->data[co] - (float)hi);
+        }
       }
     SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp->w1a_fragb), fr.size() * sizeof(_Float16)));
     SSHIP_HIP_CHECK(hipMemcpy(sp->w1a_fragb, fr.data(), fr.size() * sizeof(_Float16), hipMemcpyHostToDevice));

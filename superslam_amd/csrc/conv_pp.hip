@@ -30,6 +30,9 @@
 #ifndef SSHIP_PP_EPI
 #define SSHIP_PP_EPI -1
 #endif
+#ifndef SSHIP_PP_EPI_FUSED  // the same for the fused conv1a + conv1b kernel, whose data half-step also computes conv1a
+#define SSHIP_PP_EPI_FUSED 0
+#endif
 // role tracing (SSHIP_PP_TRACE=1 at run time) is compiled in only on request: it costs registers in the fused kernel
 #ifndef SSHIP_PP_TRACE_BUILD
 #define SSHIP_PP_TRACE_BUILD 0
@@ -37,6 +40,13 @@
 // s_setprio level of the data-movement role (0 = off; the MFMA role runs at priority 0)
 #ifndef SSHIP_PP_PRIO
 #define SSHIP_PP_PRIO 2
+#endif
+#ifndef SSHIP_PP_NBUF
+#define SSHIP_PP_NBUF 3
+#endif
+// accumulator initialisation (bias reads): 1 = at the end of the preceding data half-step, 0 = at the start of the MFMA half-step
+#ifndef SSHIP_PP_ACC_PRELOAD
+#define SSHIP_PP_ACC_PRELOAD 1
 #endif
 
 namespace sship {
@@ -70,8 +80,9 @@ struct PpWalk { int tx, ty, b; };  // wave-uniform tile coordinates of a group's
 template <int CIN, int CT, bool POOL, bool FUSE1A>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   constexpr int MT = CT / 32, NCHUNK = CIN / 64;
-  constexpr int EPI_MFMA = SSHIP_PP_EPI < 0 ? (CIN == 128 ? 2 * MT : 0) : (SSHIP_PP_EPI > 2 * MT ? 2 * MT : SSHIP_PP_EPI);
+  constexpr int EPI_MFMA = FUSE1A ? SSHIP_PP_EPI_FUSED : SSHIP_PP_EPI < 0 ? (CIN == 128 ? 2 * MT : 0) : (SSHIP_PP_EPI > 2 * MT ? 2 * MT : SSHIP_PP_EPI);
   constexpr int PIX_B = CIN * 2;  // bytes per input pixel
+  constexpr int NBUF = SSHIP_PP_NBUF;  // fragment ring depth of the MFMA loop: k-step i + NBUF - 1 is requested before the MFMAs of k-step i
   static_assert(NCHUNK * 9 * 4 * MT * 512 == P_W_HALFS, "weights must fill exactly 72 KiB");
   static_assert(!FUSE1A || CIN == 64, "conv1a fusion feeds a 64-channel layer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -181,6 +192,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   // tile-invariant geometry of this lane's (up to) 3 halo pixels: q = 32 (gw + 4k) + j -> (py, px), its LDS base and
   // the swizzle term; computed once per launch (two VGPRs per N-tile)
   int c1_pypx[FUSE1A ? NT_W : 1], c1_lds[FUSE1A ? NT_W : 1];
+  // byte selectors of the conv1a B fragment (stage_conv1a): hh = 0: [r0.b0 r0.b1 r0.b2 r1.b0] and [r1.b1 0 0 0] from (X = r1, Y = r0);
+  // hh = 1: [r1.b2 r2.b0 r2.b1 r2.b2] and [0xFF 0xFF 0 0] from (X = r2, Y = r1).  v_perm_b32: bytes 0..3 = second source,
+  // 4..7 = first source, 0x0c = 0x00, 0x0d = 0xFF.
+  const unsigned c1_selA = hh ? 0x06050402u : 0x04020100u, c1_selB = hh ? 0x0c0c0d0du : 0x0c0c0c05u;
   if constexpr (FUSE1A) {
 #pragma unroll
     for (int k = 0; k < NT_W; ++k) {
@@ -256,21 +271,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
             rp[k][r] = (gy >= 0 && gy < p.H) ? v : 0u;
           }
         }
-        // taps (r, c) = byte c of dword r; cv convertTo: float(u8) * (1/255), then the engine's fp16 input
-        _Float16 t[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) t[r][c] = (_Float16)((float)((rp[k][r] >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
-        // lanes hh = 0: taps 0..7; lanes hh = 1: tap 8, the two bias slots (1.0, 1.0) and zero padding
-        bf[k][0] = hh ? t[2][2] : t[0][0];
-        bf[k][1] = hh ? (_Float16)1.f : t[0][1];
-        bf[k][2] = hh ? (_Float16)1.f : t[0][2];
-        bf[k][3] = hh ? (_Float16)0.f : t[1][0];
-        bf[k][4] = hh ? (_Float16)0.f : t[1][1];
-        bf[k][5] = hh ? (_Float16)0.f : t[1][2];
-        bf[k][6] = hh ? (_Float16)0.f : t[2][0];
-        bf[k][7] = hh ? (_Float16)0.f : t[2][1];
+        // taps (r, c) = byte c of dword r.  K layout (matches w1a_fragb): lanes hh = 0 hold taps 0..4 in slots 0..4, lanes hh = 1
+        // taps 5..8 in slots 0..3 and the two bias slots (B = 1.0) in 4, 5 - five or six conversions per lane instead of
+        // nine.  The bytes are gathered first (two v_perm_b32 with per-lane selectors); a 0xFF byte converts to exactly
+        // 1.0 (255 * fl(1/255) rounds to 1.0f), which is how the bias slots get their ones.
+        const unsigned X = hh ? rp[k][2] : rp[k][1], Y = hh ? rp[k][1] : rp[k][0];
+        const unsigned q4 = __builtin_amdgcn_perm(X, Y, c1_selA), q2 = __builtin_amdgcn_perm(X, X, c1_selB);
+        // cv::Mat::convertTo: float(u8) * (1/255), then the engine's fp16 input
+        // (v_mul_f32 by hand: the compiler pairs the products into v_pk_mul_f32, and a packed-fp32 instruction of this wave
+        // waited for a gap in the other wave's MFMA stream - the six conv1a MFMAs then issued ~2 k clocks later)
+        auto cv8 = [](unsigned w, int byte) __attribute__((always_inline)) {
+          float r;
+          asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"((float)((w >> (8 * byte)) & 0xffu)), "v"(1.0f / 255.0f));
+          return (_Float16)r;
+        };
+        bf[k][0] = cv8(q4, 0); bf[k][1] = cv8(q4, 1); bf[k][2] = cv8(q4, 2); bf[k][3] = cv8(q4, 3);
+        bf[k][4] = cv8(q2, 0); bf[k][5] = cv8(q2, 1); bf[k][6] = (_Float16)0.f; bf[k][7] = (_Float16)0.f;
       }
       if (SSHIP_PP_TRACE_BUILD && tr_stage) ts1 = __builtin_readcyclecounter();
       const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -311,16 +327,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   };
 
   f16x_t acc[MT][2];
+  // The accumulators start from the bias (row 8 g + 4 hh + e of M-tile m is register 4 g + e: one ds_read_b128 per quad,
+  // straight into the accumulator registers).  The reads are issued at the end of the preceding data half-step, so the MFMA
+  // half-step opens with its fragment reads only.
+  auto acc_init = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(s_bias + n * CT + m * 32 + hh * 4 + g * 8);
+          acc[m][n][4 * g + 0] = b4.x; acc[m][n][4 * g + 1] = b4.y; acc[m][n][4 * g + 2] = b4.z; acc[m][n][4 * g + 3] = b4.w;
+        }
+  };
   // ---------------- MFMA half-step: 36 k-steps of one 64-channel chunk, fragments triple-buffered ----------------
-  // Chunk 0 starts the accumulators from the bias (row 8 g + 4 hh + e of M-tile m is register 4 g + e: one ds_read_b128 per
-  // quad, straight into the accumulator registers); a tile's accumulators are defined and consumed inside one loop iteration.
   auto mfma_item = [&](auto chunk_c) __attribute__((always_inline)) {
     constexpr int chunk = decltype(chunk_c)::value;
     const _Float16* wc = s_w + chunk * (9 * 4 * MT * 512) + lane * 8;
     const _Float16* ib = my_in + (gw * 2) * P_TWH * 64;
     // one wave per SIMD feeds the matrix pipe here, so LDS latency must be covered by this wave alone: fragments are
     // triple-buffered, the ds_reads of k-step i+2 are issued (and pinned) before the MFMAs of k-step i.
-    h8_t fa[3][MT], fb[3][2];
+    h8_t fa[NBUF][MT], fb[NBUF][2];
     auto load_frags = [&](int idx, int buf) __attribute__((always_inline)) {
       const int tap = idx >> 2, ks = idx & 3, ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
@@ -328,27 +356,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) fb[buf][n] = *reinterpret_cast<const h8_t*>(ib + (n + ky) * P_TWH * 64 + boff[kx][ks]);
     };
-    load_frags(0, 0);
-    load_frags(1, 1);
-    if constexpr (chunk == 0) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *reinterpret_cast<const float4*>(s_bias + n * CT + m * 32 + hh * 4 + g * 8);
-            acc[m][n][4 * g + 0] = b4.x; acc[m][n][4 * g + 1] = b4.y; acc[m][n][4 * g + 2] = b4.z; acc[m][n][4 * g + 3] = b4.w;
-          }
-    }
+    for (int i = 0; i < NBUF - 1; ++i) load_frags(i, i);
+    if constexpr (chunk == 0 && !SSHIP_PP_ACC_PRELOAD) acc_init();
 #pragma unroll
     for (int idx = 0; idx < 36; ++idx) {
-      if (idx + 2 < 36) load_frags(idx + 2, (idx + 2) % 3);
+      if (idx + NBUF - 1 < 36) load_frags(idx + NBUF - 1, (idx + NBUF - 1) % NBUF);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(fa[idx % 3][m], fb[idx % 3][n], acc[m][n]);
+        for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(fa[idx % NBUF][m], fb[idx % NBUF][n], acc[m][n]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   const bool tr_lane = SSHIP_PP_TRACE_BUILD && p.trace && gw == 0 && lane == 0;
   unsigned long long t0 = 0, t1 = 0;
   // data half-step after MFMA item (it, chunk): epilogue if that was the tile's last chunk; stage item + 1; prefetch item + 2
-  auto data_role = [&](bool do_epi, bool do_stage, bool do_prefetch, int pf_chunk, bool tr) __attribute__((always_inline)) {
+  auto data_role = [&](bool do_epi, bool do_stage, bool do_prefetch, int pf_chunk, bool init_acc, bool tr) __attribute__((always_inline)) {
     if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(SSHIP_PP_PRIO);
     if (tr) t0 = __builtin_readcyclecounter();
     if (do_epi && EPI_MFMA < 2 * MT) epilogue(EPI_MFMA, 2 * MT);
@@ -429,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     if (do_stage) { if constexpr (FUSE1A) stage_conv1a(tr); else stage_in(); }
     if (tr) { t1 = __builtin_readcyclecounter(); trow[1] = t1 - t0; t0 = t1; }
     if (do_prefetch) { if constexpr (FUSE1A) prefetch_u8(); else prefetch_in(pf_chunk); }
+    if (SSHIP_PP_ACC_PRELOAD && init_acc) acc_init();  // for the tile whose first MFMA half-step comes next
     if (tr) { t1 = __builtin_readcyclecounter(); trow[2] = t1 - t0; t0 = t1; }
     __syncthreads();
     if (tr) trow[4] = __builtin_readcyclecounter() - t0;
@@ -452,18 +471,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   __syncthreads();  // weights and bias are in LDS
   if (grp == 1) __syncthreads();  // group 1 runs one half-step behind group 0
   // first data half-step: item 0 into LDS, prefetch item 1
-  data_role(false, T_mine > 0, NCHUNK > 1 ? T_mine > 0 : T_mine > 1, NCHUNK > 1 ? 1 : 0, false);
+  data_role(false, T_mine > 0, NCHUNK > 1 ? T_mine > 0 : T_mine > 1, NCHUNK > 1 ? 1 : 0, T_mine > 0, false);
 #pragma unroll 1
   for (int it = 0; it < T_mine; ++it) {
     const bool more = it + 1 < T_mine, tr = tr_lane && it == 2;
     if constexpr (NCHUNK == 1) {
       mfma_role(c0, tr);
-      data_role(true, more, it + 2 < T_mine, 0, tr);
+      data_role(true, more, it + 2 < T_mine, 0, more, tr);
     } else {
       mfma_role(c0, tr);
-      data_role(false, true, more, 0, tr);          // stage chunk 1 of this tile, prefetch chunk 0 of the next
+      data_role(false, true, more, 0, false, tr);   // stage chunk 1 of this tile, prefetch chunk 0 of the next
       mfma_role(c_last, false);
-      data_role(true, more, more, 1, false);        // epilogue; stage chunk 0 of the next tile, prefetch its chunk 1
+      data_role(true, more, more, 1, more, false);  // epilogue; stage chunk 0 of the next tile, prefetch its chunk 1
     }
   }
 #pragma unroll 1
