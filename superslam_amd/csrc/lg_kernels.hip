@@ -201,39 +201,31 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     for (int r = 0; r < 16; ++r) { o[t][0][r] = 0.f; o[t][1][r] = 0.f; }
   }
   const int ntiles = active ? (nk + 31) >> 5 : 0;
-  // K and V^T fragments are prefetched ONE FULL TILE ahead (loads for tile kt+4 are issued before the MFMAs and
-  // softmax of tile kt), so ~1k cycles of L2 latency hide behind a whole iteration instead of a few MFMAs.
-  h8_t kf[4], vf[2][2];
-  {
-    const int kt0 = min(ksp, nt32 - 1);
+  // K and V^T fragments are prefetched ONE FULL TILE ahead (loads for tile kt + KS are issued before the MFMAs and
+  // softmax of tile kt), so ~1k cycles of L2 latency hide behind a whole iteration instead of a few MFMAs.  Two register
+  // sets, used alternately by the two halves of the unrolled key loop: no fragment copies at the end of an iteration
+  // (they were 41 of the ~190 VALU instructions of an iteration, and this loop is VALU-bound).
+  h8_t kfA[4], vfA[2][2], kfB[4], vfB[2][2];
+  auto fetch = [&](h8_t (&kf)[4], h8_t (&vf)[2][2], int kt) __attribute__((always_inline)) {
+    const int ktc = min(kt, nt32 - 1);  // clamped: a prefetch past the end re-reads a valid tile and is discarded
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)kt0 * 4 + ks) * 512 + lane * 8);
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)ktc * 4 + ks) * 512 + lane * 8);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)kt0 * 2 + kk) * 2 + mt) * 512 + lane * 8);
-  }
-  if (SSHIP_ATTN_TRACE_BUILD && trace) tr1 = __builtin_readcyclecounter();
-  for (int kt = ksp; kt < ntiles; kt += KS) {
+        vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)ktc * 2 + kk) * 2 + mt) * 512 + lane * 8);
+  };
+  const h2_t ones2 = {(_Float16)1.f, (_Float16)1.f};
+  // one key tile for the QT query tiles of this wave
+  auto tile = [&](const h8_t (&kf)[4], const h8_t (&vf)[2][2], int kt) __attribute__((always_inline)) {
     const int k0 = kt * 32;
-    h8_t kn[4], vn[2][2];
-    const int ktn = min(kt + KS, nt32 - 1);  // clamped: the last prefetch re-reads a valid tile and is discarded
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kn[ks] = *reinterpret_cast<const h8_t*>(K + ((size_t)ktn * 4 + ks) * 512 + lane * 8);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        vn[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)ktn * 2 + kk) * 2 + mt) * 512 + lane * 8);
-    __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above this tile's MFMAs / softmax
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      f16x_t st;
+      const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f16x_t st = mfma32(kf[0], qf[t][0], zero16);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
+      for (int ks = 1; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
       if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
         int kb = k0 + 4 * hh;
         asm volatile("" : "+v"(kb));  // keeps the 16 key indices inside the branch (hipcc hoisted them into every iteration)
@@ -257,26 +249,37 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
         for (int r = 0; r < 16; ++r) { o[t][0][r] *= alpha; o[t][1][r] *= alpha; }
         m[t] = m_new;
       }
-      float ls = 0.f;
-      float pr[16];
+      // P in fp16 (the PV operand); the row sum is taken over exactly these rounded values: v_dot2_f32_f16 against ones, fp32
+      // accumulate - half the instructions of sixteen fp32 adds
+      float ls0 = 0.f, ls1 = 0.f;
+      h8_t pb[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(st[r] - m[t]); ls += pr[r]; }
-      l[t] += ls;
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        h8_t pb;
+        for (int e = 0; e < 8; e += 2) {
+          const h2_t pp = {(_Float16)__builtin_amdgcn_exp2f(st[8 * kk + e] - m[t]), (_Float16)__builtin_amdgcn_exp2f(st[8 * kk + e + 1] - m[t])};
+          pb[kk][e] = pp[0]; pb[kk][e + 1] = pp[1];
+          if (kk == 0) ls0 = __builtin_amdgcn_fdot2(pp, ones2, ls0, false);
+          else ls1 = __builtin_amdgcn_fdot2(pp, ones2, ls1, false);
+        }
+      l[t] += ls0 + ls1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pb[e] = (_Float16)pr[8 * kk + e];
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) o[t][mt] = mfma32(vf[kk][mt], pb, o[t][mt]);
-      }
+        for (int mt = 0; mt < 2; ++mt) o[t][mt] = mfma32(vf[kk][mt], pb[kk], o[t][mt]);
     }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[ks] = kn[ks];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) vf[kk][mt] = vn[kk][mt];
+  };
+  fetch(kfA, vfA, ksp);
+  if (SSHIP_ATTN_TRACE_BUILD && trace) tr1 = __builtin_readcyclecounter();
+  for (int kt = ksp; kt < ntiles; kt += 2 * KS) {
+    fetch(kfB, vfB, kt + KS);
+    __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above this tile's MFMAs / softmax
+    tile(kfA, vfA, kt);
+    if (kt + KS < ntiles) {
+      fetch(kfA, vfA, kt + 2 * KS);
+      __builtin_amdgcn_sched_barrier(0);
+      tile(kfB, vfB, kt + KS);
+    }
   }
   if (SSHIP_ATTN_TRACE_BUILD && trace) tr2 = __builtin_readcyclecounter();
   // ---- merge the KS key-partials of every query group ----
