@@ -45,6 +45,22 @@ def _ulp16(a, b):
     return np.abs(key(a) - key(b))
 
 
+def _assert_same_features_fp16(name, base, alt):
+    """Two conv kernels with different fp32 summation orders: same keypoint set (>= 98 % IoU), scores within 2e-2 (the peaky
+    synthetic detector amplifies logit differences), descriptors of common keypoints within 1e-2 (unit vectors, fp16)."""
+    for tag in ("l", "r"):
+        kb, ka = base["kp_" + tag], alt["kp_" + tag]
+        ib = {(int(x), int(y)): i for i, (x, y, _) in enumerate(kb)}
+        ia = {(int(x), int(y)): i for i, (x, y, _) in enumerate(ka)}
+        common = sorted(set(ib) & set(ia))
+        iou = len(common) / max(1, len(set(ib) | set(ia)))
+        rows_b = np.array([ib[c] for c in common]); rows_a = np.array([ia[c] for c in common])
+        ds = np.abs(kb[rows_b, 2] - ka[rows_a, 2]).max()
+        dd = np.abs(base["d_" + tag][rows_b].astype(np.float32) - alt["d_" + tag][rows_a].astype(np.float32)).max()
+        print(name, tag, "IoU", round(iou, 4), "score max|d|", float(ds), "descriptor max|d|", float(dd))
+        assert iou >= 0.98 and ds < 2e-2 and dd < 1e-2
+
+
 def test_dense_descriptor_branch_agrees_with_sparse_head(weights_dir, tmp_path):
     """SUPERSLAM_HIP_DESC=dense (dense convDa + gather kernel): identical keypoints (same encoder / detector) and
     descriptors within one fp16 ulp of the default head evaluated at the keypoints only (same operands, same k order)."""
@@ -64,17 +80,17 @@ def test_strip_conv_kernel_agrees_with_ping_pong(weights_dir, tmp_path):
     detector amplifies logit differences), descriptors of common keypoints within 1e-2 (unit vectors, fp16)."""
     base = _run({}, weights_dir, tmp_path, "default")
     alt = _run({"SUPERSLAM_HIP_CONV": "strip"}, weights_dir, tmp_path, "strip")
-    for tag in ("l", "r"):
-        kb, ka = base["kp_" + tag], alt["kp_" + tag]
-        ib = {(int(x), int(y)): i for i, (x, y, _) in enumerate(kb)}
-        ia = {(int(x), int(y)): i for i, (x, y, _) in enumerate(ka)}
-        common = sorted(set(ib) & set(ia))
-        iou = len(common) / max(1, len(set(ib) | set(ia)))
-        rows_b = np.array([ib[c] for c in common]); rows_a = np.array([ia[c] for c in common])
-        ds = np.abs(kb[rows_b, 2] - ka[rows_a, 2]).max()
-        dd = np.abs(base["d_" + tag][rows_b].astype(np.float32) - alt["d_" + tag][rows_a].astype(np.float32)).max()
-        print("strip", tag, "IoU", round(iou, 4), "score max|d|", float(ds), "descriptor max|d|", float(dd))
-        assert iou >= 0.98 and ds < 2e-2 and dd < 1e-2
+    _assert_same_features_fp16("strip", base, alt)
+
+
+def test_ct32_conv_kernel_agrees_with_the_64_row_tile_kernel(weights_dir, tmp_path):
+    """SUPERSLAM_HIP_CONV128=ct32: the 128-input-channel layers on the 32-row-tile kernel of conv_pp.hip (two 64-channel
+    chunks) instead of conv_pp128.hip (four 32-channel chunks, weight ring by LDS-DMA, buffer-addressed staging).  Same
+    operands, different k order (chunk size) in the fp32 accumulation: compared by the suite's fp16 tolerances.
+    The worker's 200 x 328 image gives those layers odd tile counts, partial edge tiles and a one-tile-per-group tail."""
+    base = _run({}, weights_dir, tmp_path, "default")
+    alt = _run({"SUPERSLAM_HIP_CONV128": "ct32"}, weights_dir, tmp_path, "ct32")
+    _assert_same_features_fp16("ct32", base, alt)
 
 
 def test_mfma_probe_reports_a_plausible_rate():
