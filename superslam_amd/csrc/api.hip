@@ -1267,6 +1267,11 @@ struct sship_lg {
   int debug_layers = kLgLayers;  // sship_lg_debug_set_layers
   int last_pairs = 0;
   PinBuf h_kp, h_lens, h_m0, h_ms0, h_desc;
+  // throughput batches run their transformer layers as two half-batches on two streams (lg_forward): the second stream and the
+  // fork / join events
+  static constexpr int kAux = 3;
+  hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr};
 };
 
 extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, int max_kp, int max_pairs, sship_lg** out) {
@@ -1278,6 +1283,7 @@ extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, in
   std::unique_ptr<sship_lg> lg(new sship_lg());
   lg->image_w = image_w; lg->image_h = image_h; lg->max_kp = max_kp; lg->max_pairs = max_pairs;
   lg->NP = (max_kp + 31) / 32 * 32;  // 32-token granularity: 600 keypoints -> 608 tokens (128-granular padding was 6.7 % dead work)
+
   const size_t S = 2 * (size_t)max_pairs, T = S * lg->NP, NP = lg->NP;
   SSHIP_HIP_CHECK(lg->x.ensure(T * 256 * 2));
   SSHIP_HIP_CHECK(lg->rope.ensure(T * 64 * 4));
@@ -1306,10 +1312,17 @@ extern "C" int sship_lg_create(sship_lg_weights* w, int image_w, int image_h, in
   SSHIP_HIP_CHECK(hipMemset(lg->k.p, 0, lg->k.bytes));
   SSHIP_HIP_CHECK(hipMemset(lg->vt.p, 0, lg->vt.bytes));
   SSHIP_HIP_CHECK(hipMemset(lg->ctx.p, 0, lg->ctx.bytes));
-  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&lg->stream, hipStreamDefault));
+  // from here on the handle owns streams / events: hand it to sship_lg_destroy on any failure (w is still null: nothing to release)
+  std::unique_ptr<sship_lg, void (*)(sship_lg*)> owned(lg.release(), sship_lg_destroy);
+  SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&owned->stream, hipStreamDefault));
+  for (int i = 0; i < sship_lg::kAux; ++i) {
+    SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&owned->aux[i], hipStreamNonBlocking));
+    SSHIP_HIP_CHECK(hipEventCreateWithFlags(&owned->ev_join[i], hipEventDisableTiming));
+  }
+  SSHIP_HIP_CHECK(hipEventCreateWithFlags(&owned->ev_fork, hipEventDisableTiming));
   sship_lg_weights_retain(w);
-  lg->w = w;
-  *out = lg.release();
+  owned->w = w;
+  *out = owned.release();
   return SSHIP_OK;
 }
 extern "C" void sship_lg_destroy(sship_lg* lg) {
@@ -1317,6 +1330,11 @@ extern "C" void sship_lg_destroy(sship_lg* lg) {
   if (!lg) return;
   (void)hipDeviceSynchronize();
   if (lg->stream) (void)hipStreamDestroy(lg->stream);
+  for (int i = 0; i < sship_lg::kAux; ++i) {
+    if (lg->aux[i]) (void)hipStreamDestroy(lg->aux[i]);
+    if (lg->ev_join[i]) (void)hipEventDestroy(lg->ev_join[i]);
+  }
+  if (lg->ev_fork) (void)hipEventDestroy(lg->ev_fork);
   sship_lg_weights_release(lg->w);
   delete lg;
 }
@@ -1389,24 +1407,57 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   lg->last_pairs = pairs;
   // 3 launches per block: [projection fused into the previous FFN's tail] -> attention -> FFN(+ next projection).
   static const bool igemm_qkv0 = getenv("SUPERSLAM_HIP_LG_QKV0") && std::string(getenv("SUPERSLAM_HIP_LG_QKV0")) == "igemm";  // A/B
-  if (igemm_qkv0) SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
-  else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], x, d, /*rope_segs=*/2, /*t_seg=*/2, rope, q, k, vt, s));
-  g_timer.mark("fe_lg_stereo_match:posenc_qkv0", s);
   const int n_layers = lg->debug_layers;  // kLgLayers except under sship_lg_debug_set_layers (test-only)
-  for (int i = 0; i < n_layers; ++i) {
-    // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
-    launch_lg_attention(q, k, vt, lens, d, false, ctx, s);
-    launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], ctx, x, d, &w->cqkv_t[i], true, /*rope_segs=*/0,
-                  /*t_seg=*/1, rope, q, k, vt, nullptr, nullptr, 0.f, nullptr, s);
-    // CrossBlock (qk shared by both directions; sequence s attends to s^1); its FFN emits the next layer's Wqkv,
-    // or final_proj + matchability after the last layer
-    launch_lg_attention(q, q, vt, lens, d, true, ctx, s);
-    if (i + 1 < kLgLayers)
-      launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], ctx, x, d, &w->qkv_t[i + 1], true, 2, 2, rope, q, k,
-                    vt, nullptr, nullptr, 0.f, nullptr, s);
-    else
-      launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], ctx, x, d, &w->final_t, false, 0, 0, rope, q, k, vt,
-                    lg->md.as<_Float16>(), w->match_w, w->match_b, lg->logsig.as<float>(), s);
+  // the layer stack of pairs [p0, p0 + np) on stream st: every buffer is sequence-major, pairs are independent
+  auto layers = [&](int p0, int np, hipStream_t st) -> int {
+    const LgDims ds{2 * np, lg->NP};
+    const size_t tok = (size_t)2 * p0 * lg->NP;
+    _Float16 *xs = x + tok * 256, *qs = q + tok * 256, *ks = k + tok * 256, *vs = vt + tok * 256, *cs = ctx + tok * 256;
+    const float* rs = rope + tok * 64;
+    const int* ls = lens + 2 * p0;
+    if (igemm_qkv0) SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st));
+    else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st));
+    for (int i = 0; i < n_layers; ++i) {
+      // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
+      launch_lg_attention(qs, ks, vs, ls, ds, false, cs, st);
+      launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], cs, xs, ds, &w->cqkv_t[i], true, /*rope_segs=*/0,
+                    /*t_seg=*/1, rs, qs, ks, vs, nullptr, nullptr, 0.f, nullptr, st);
+      // CrossBlock (qk shared by both directions; sequence s attends to s^1); its FFN emits the next layer's Wqkv,
+      // or final_proj + matchability after the last layer
+      launch_lg_attention(qs, qs, vs, ls, ds, true, cs, st);
+      if (i + 1 < kLgLayers)
+        launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], cs, xs, ds, &w->qkv_t[i + 1], true, 2, 2, rs, qs, ks,
+                      vs, nullptr, nullptr, 0.f, nullptr, st);
+      else
+        launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], cs, xs, ds, &w->final_t, false, 0, 0, rs, qs, ks, vs,
+                      lg->md.as<_Float16>() + tok * 256, w->match_w, w->match_b, lg->logsig.as<float>() + tok, st);
+    }
+    SSHIP_HIP_CHECK(hipGetLastError());
+    return SSHIP_OK;
+  };
+  // Throughput batches: two half-batches on two streams.  Every LightGlue launch is a whole number of workgroup "rounds" over
+  // the 512 workgroup slots plus a partly filled last one (FFN: 1216 tiles = 2.4 rounds at 64 pairs - a third of the launch
+  // runs at 37 % occupancy); a second, independent stream of the same kernels fills those tails, and an attention workgroup
+  // (70 KB LDS, transcendental-bound) can share a CU with an FFN workgroup (79 KB, matrix-bound) of the other half.
+  // Only when each half still qualifies for the throughput kernels; SUPERSLAM_HIP_LG_SPLIT=1 turns it off (A/B runs).
+  static const int split_env = getenv("SUPERSLAM_HIP_LG_SPLIT") ? atoi(getenv("SUPERSLAM_HIP_LG_SPLIT")) : 0;
+  int parts = 1;
+  if (split_env >= 1 && split_env <= 1 + sship_lg::kAux) parts = std::min(split_env, pairs);  // forced (1 = off)
+  else if ((size_t)2 * (pairs / 2) * lg->NP / 64 >= (size_t)2 * cu_count()) parts = 2;
+  if (parts > 1) {
+    SSHIP_HIP_CHECK(hipEventRecord(lg->ev_fork, s));
+    int p0 = pairs / parts;  // part 0 (on s) is launched last: the auxiliary streams are already busy by then
+    for (int i = 1; i < parts; ++i) {
+      const int np = i + 1 < parts ? pairs / parts : pairs - p0;
+      SSHIP_HIP_CHECK(hipStreamWaitEvent(lg->aux[i - 1], lg->ev_fork, 0));
+      if (int rc = layers(p0, np, lg->aux[i - 1])) return rc;
+      SSHIP_HIP_CHECK(hipEventRecord(lg->ev_join[i - 1], lg->aux[i - 1]));
+      p0 += np;
+    }
+    if (int rc = layers(0, pairs / parts, s)) return rc;
+    for (int i = 1; i < parts; ++i) SSHIP_HIP_CHECK(hipStreamWaitEvent(s, lg->ev_join[i - 1], 0));
+  } else {
+    if (int rc = layers(0, pairs, s)) return rc;
   }
   SSHIP_HIP_CHECK(hipGetLastError());
   g_timer.mark("fe_lg_stereo_match:layers_x9", s);
