@@ -736,6 +736,13 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
       if (int rc = upload_conv_q(w->data.data(), l.cout, l.cin, *l.dst)) return rc;
     if (std::string(l.name) == "convDb")
       if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, 1, 32, sp->cDb32)) return rc;
+    if (std::string(l.name) == "convPb") {  // the streaming kernel reads the plain matrix, [80][256] fp16 (sp_convs.hip: k_convpb_stream)
+      std::vector<_Float16> plain((size_t)80 * 256, (_Float16)0.f);
+      for (int co = 0; co < 65; ++co)
+        for (int ci = 0; ci < 256; ++ci) plain[(size_t)co * 256 + ci] = (_Float16)w->data[(size_t)co * 256 + ci];
+      SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&l.dst->w_q), plain.size() * sizeof(_Float16)));
+      SSHIP_HIP_CHECK(hipMemcpy(l.dst->w_q, plain.data(), plain.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    }
   }
   {
     const Tensor* w = find_tensor(sd, "conv1a.weight", {64, 1, 3, 3}, err);

@@ -55,7 +55,7 @@ void launch_bgr2gray(const uint8_t* in, int n, uint8_t* out, hipStream_t s);
 // ---- sp_convs.hip : MFMA implicit-GEMM layers of SuperPoint ----
 struct ConvW {          // one packed conv / linear layer on the device
   _Float16* w = nullptr;  // packed A-fragment order (igemm.h)
-  _Float16* w_q = nullptr;  // optional second packing: 64-row cout tiles over 32-channel chunks (conv_pp128.hip)
+  _Float16* w_q = nullptr;  // optional second form: 64-row cout tiles over 32-channel chunks (conv_pp128.hip); convPb: the plain [80][256] matrix
   float* bias = nullptr;  // [cout_pad]
   int cin = 0, cout = 0, cout_pad = 0, ks = 1, ct = 64;
 };

@@ -1,8 +1,11 @@
 // SuperPoint's 1x1 layers on the implicit-GEMM template (igemm.h) and the fused descriptor head.
 // (The 3x3 layers live in conv_strip.hip / conv_pp.hip.)
 //   convDb : 1x1 256->256, raw fp16 - dense grid only for sship_sp_dense; extraction uses k_desc_head_gather below
-//   convPb : 1x1 256->65, fp32 logits in an 80-wide row (softmax happens in the heatmap kernel)
+//   convPb : 1x1 256->65, fp32 logits in a 68-wide row (softmax happens in the heatmap kernel): k_convpb_stream below
 // reference: utils/convert_superpoint_to_onnx.py:38-64,77,88.
+#include <cstdlib>
+#include <string>
+
 #include "igemm.h"
 #include "kernels.h"
 
@@ -22,11 +25,93 @@ hipError_t sp_conv1x1_f16(const ConvW& w, const _Float16* in, _Float16* out, int
   return launch_igemm<1, 256, 128, 4, EpiF16<false, false>>(a, w.cout_pad, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// convPb as a streaming kernel: 1x1, 256 -> 65, fp32 logits.  The layer is HBM-bound (4.1 MB of fp16 in, 2.2 MB of fp32
+// out per image, 1.06 GFLOP) and the implicit-GEMM template spent its time on two barriers per 64-channel stage and on
+// re-staging 48 KB of weights per 128-pixel workgroup.  Here nothing goes through LDS but one weight M-tile:
+//   * v_mfma_f32_16x16x32_f16 with the pixels as the N operand: lane l holds 8 consecutive channels (k-block l >> 4) of
+//     pixel l & 15, i.e. a B fragment is a plain 16-byte global load and the four lanes of a pixel cover one 64-byte
+//     sector per instruction; a 16-pixel tile is 8 loads per lane, prefetched one tile ahead into a second register set;
+//   * the weights of output rows 0..63 live in registers for the whole kernel (4 M-tiles x 8 k-steps = 128 VGPRs,
+//     read once per wave), the fifth M-tile (row 64 = the dustbin channel, rows 65..79 zero) comes from LDS (8 KiB);
+//   * the accumulators start from the bias (LDS); a lane ends up with 4 consecutive channels of its pixel per M-tile:
+//     16-byte stores, 64 contiguous bytes per pixel and instruction.
+// 40 MFMAs (640 matrix-pipe clocks) per 16 pixels against ~1.3 KB of HBM traffic per pixel: memory-bound by design.
+// ---------------------------------------------------------------------------------------------------
+typedef float f4x_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void k_convpb_stream(const _Float16* __restrict__ in, const _Float16* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int P,
+                                                          int ostride) {
+  __shared__ __attribute__((aligned(16))) _Float16 s_a4[8 * 512];  // A fragments of M-tile 4, [k-step][lane][8]
+  const int lane = threadIdx.x & 63, n = lane & 15, kb = lane >> 4;
+  for (int u = threadIdx.x; u < 8 * 64; u += 256) {
+    const int ks = u >> 6, l = u & 63;
+    *reinterpret_cast<uint4*>(s_a4 + u * 8) = *reinterpret_cast<const uint4*>(w + (size_t)(64 + (l & 15)) * 256 + ks * 32 + (l >> 4) * 8);
+  }
+  h8_t a[4][8];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) a[m][ks] = *reinterpret_cast<const h8_t*>(w + (size_t)(16 * m + n) * 256 + ks * 32 + kb * 8);
+  __shared__ __attribute__((aligned(16))) float s_b[80];  // bias, rows 65..79 zero: the accumulators start from it
+  if (threadIdx.x < 80) s_b[threadIdx.x] = threadIdx.x < 65 ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int ntiles = (P + 15) >> 4, nwaves = gridDim.x * 4;
+  const _Float16* src = in + kb * 8;
+  h8_t fA[8], fB[8];
+  auto fetch = [&](h8_t (&f)[8], int t) __attribute__((always_inline)) {
+    const int pix = min(min(t, ntiles - 1) * 16 + n, P - 1);  // clamped: a prefetch past the end re-reads a valid pixel
+    const _Float16* p = src + (size_t)pix * 256;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) f[ks] = *reinterpret_cast<const h8_t*>(p + ks * 32);
+  };
+  auto tile = [&](const h8_t (&f)[8], int t) __attribute__((always_inline)) {
+    f4x_t acc[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) acc[m] = *reinterpret_cast<const f4x_t*>(s_b + 16 * m + 4 * kb);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const h8_t a4 = *reinterpret_cast<const h8_t*>(s_a4 + (ks * 64 + lane) * 8);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][ks], f[ks], acc[m], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4, f[ks], acc[4], 0, 0, 0);
+    }
+    const int pix = t * 16 + n;
+    if (pix < P) {
+      float* o = out + (size_t)pix * ostride + 4 * kb;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) *reinterpret_cast<f4x_t*>(o + 16 * m) = acc[m];
+      if (kb == 0) o[64] = acc[4][0];
+    }
+  };
+  const int t0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  fetch(fA, t0);
+  for (int t = t0; t < ntiles; t += 2 * nwaves) {
+    fetch(fB, t + nwaves);
+    __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above this tile's MFMAs
+    tile(fA, t);
+    if (t + nwaves < ntiles) {
+      fetch(fA, t + 2 * nwaves);
+      __builtin_amdgcn_sched_barrier(0);
+      tile(fB, t + nwaves);
+    }
+  }
+}
+
+// w.w_q: the plain fp16 weight matrix [80][256] (rows 65..79 zero), w.bias: [>= 80] floats
 hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int ostride, int B, int H, int W,
                           hipStream_t s) {
+  if (w.cin != 256) return hipErrorInvalidValue;
+  static const bool use_igemm = getenv("SUPERSLAM_HIP_CONVPB") && std::string(getenv("SUPERSLAM_HIP_CONVPB")) == "igemm";  // A/B
+  if (w.w_q && w.cout == 65 && ostride >= 68 && ostride % 4 == 0 && !use_igemm) {
+    const int P = B * H * W;
+    int wgs = 2 * cu_count();
+    if (wgs * 4 > (P + 15) / 16) wgs = ((P + 15) / 16 + 3) / 4;
+    hipLaunchKernelGGL(k_convpb_stream, dim3(wgs), dim3(256), 0, s, in, w.w_q, w.bias, out, P, ostride);
+    return hipGetLastError();
+  }
   IgemmArgs a = conv_args(w, in, B, H, W);
   a.out0 = out; a.ostride = ostride;
-  if (w.cin != 256) return hipErrorInvalidValue;
   return launch_igemm<1, 256, 96, 4, EpiF32>(a, w.cout_pad, s);  // 65 rows: three M-tiles, not four
 }
 
