@@ -361,7 +361,7 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
               B * (65 * Hc * Wc * 4 + n_cand_bytes), "fp32 logits [65,Hc,Wc] read once + ~7k candidates x 8 B written, per image",
               B * (80 * Hc * Wc * 4 + n_cand_bytes))
     ms_pb = layer_ms["convPb"]
-    hbm_entry("igemm convPb (1x1, 256 -> 65, fp32 logits)", ms_pb, B * (256 * Hc * Wc * 2 + 65 * Hc * Wc * 4),
+    hbm_entry("k_convpb_stream convPb (1x1, 256 -> 65, fp32 logits)", ms_pb, B * (256 * Hc * Wc * 2 + 65 * Hc * Wc * 4),
               "fp16 convPa map read + fp32 logits written, per image", B * (256 * Hc * Wc * 2 + 80 * Hc * Wc * 4))
     ms_topk, _ = sp_layer(13)
     hbm_entry("k_topk (radix select + bitonic sort + keypoints/cells)", ms_topk, B * (n_cand_bytes + K * 20),

@@ -530,6 +530,7 @@ static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
 }
 
 hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s) {
+  if ((size_t)H * W * w.cin * 2 >= 0x7f000000ull) return hipErrorInvalidValue;  // staging offsets inside one image are 32-bit
   PpArgs a{};
   a.in = in; a.wpack = w.w; a.bias = w.bias; a.out = out; a.B = B; a.H = H; a.W = W; a.cout = w.cout;
   if (w.cin == 64 && w.ct == 64) return pool ? launch_pp<64, 64, true, false>(a, s) : launch_pp<64, 64, false, false>(a, s);
