@@ -93,6 +93,48 @@ def test_ct32_conv_kernel_agrees_with_the_64_row_tile_kernel(weights_dir, tmp_pa
     _assert_same_features_fp16("ct32", base, alt)
 
 
+def test_streaming_convpb_agrees_with_the_implicit_gemm_template(weights_dir, tmp_path):
+    """SUPERSLAM_HIP_CONVPB=igemm: detector logits through the generic 1x1 kernel (32x32x16 MFMA, LDS-staged) instead of
+    k_convpb_stream (16x16x32 MFMA, operands straight from global memory).  Different k grouping inside the matrix
+    instructions: compared by the suite's fp16 tolerances."""
+    base = _run({}, weights_dir, tmp_path, "default")
+    alt = _run({"SUPERSLAM_HIP_CONVPB": "igemm"}, weights_dir, tmp_path, "igemm")
+    _assert_same_features_fp16("convPb igemm", base, alt)
+
+
+_LG_WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from superslam_amd import LightGlue, _lib
+_lib.init(0)
+P, K = 64, 600
+lg = LightGlue({lg_path!r}, 1376, 376, max_keypoints=K, max_pairs=P); assert lg.initialize(), lg.last_error
+g = torch.Generator().manual_seed(5)
+kp = (torch.rand((2 * P, K, 3), generator=g) * torch.tensor([1376.0, 376.0, 1.0])).cuda()
+ds = torch.nn.functional.normalize(torch.randn((2 * P, K, 256), generator=g), dim=-1).half().cuda()
+n = torch.randint(300, K + 1, (2 * P,), generator=g, dtype=torch.int32).cuda()
+m, sc = lg.match_batch_device(kp, n, ds)
+torch.cuda.synchronize()
+np.savez({out!r}, m=m.cpu().numpy(), s=sc.cpu().numpy())
+"""
+
+
+def test_two_stream_lightglue_is_bit_identical_to_one_stream(weights_dir, tmp_path):
+    """lg_forward runs the layer stack of a 64-pair batch as two half-batches on two streams (SUPERSLAM_HIP_LG_SPLIT=1: one
+    stream).  Pairs are independent and both halves use the same kernels, so matches and scores must be identical bit for
+    bit - a missing fork / join edge or an overlapping buffer slice shows up as a difference (ragged counts per sequence)."""
+    outs = []
+    for name, env in (("split", {}), ("nosplit", {"SUPERSLAM_HIP_LG_SPLIT": "1"})):
+        out = str(tmp_path / (name + ".npz"))
+        code = _LG_WORKER.format(root=ROOT, lg_path=weights_dir["lg_path"], out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    np.testing.assert_array_equal(outs[0]["m"], outs[1]["m"])
+    np.testing.assert_array_equal(outs[0]["s"], outs[1]["s"])
+    print("two-stream LightGlue: 64 pairs,", int((outs[0]["m"] >= 0).sum()), "matches, identical")
+
+
 def test_mfma_probe_reports_a_plausible_rate():
     import ctypes as C
 
