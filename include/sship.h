@@ -275,7 +275,8 @@ int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int i
  * Same for one stage of the matcher, over the state the last match call left on this handle, timed with hipEvents on the
  * handle's stream: 0 first Wqkv projection, 1 self attention, 2 cross attention (both directions), 3 SelfBlock FFN + the
  * fused [to_qk|to_v] projection, 4 CrossBlock FFN + the fused next Wqkv, 5 last CrossBlock FFN + final_proj + matchability,
- * 6 assignment similarity, 7 double log-softmax + mutual arg-max + filter (five kernels). */
+ * 6 assignment pass 1 (similarity tiles + row / column log-sum-exp), 7 assignment pass 2 (similarity tiles + row / column
+ * arg-max of the double log-softmax scores). */
 int sship_lg_bench_stage(sship_lg* lg, int stage, int iters, float* avg_ms);
 
 /* Measurement aid for the roofline line: the v_mfma_f32_32x32x16_f16 rate (TFLOP/s) the device sustains from registers

@@ -1378,6 +1378,9 @@ extern "C" int sship_lg_debug_read(sship_lg* lg, int what, int index, int rows, 
     }
     case SSHIP_LG_DEBUG_SIM: {  // assignment similarity of pair `index`: f32 [NP][NP]
       if (index >= S / 2 || cols <= 0 || cols > NP) return fail(SSHIP_ERR_INVALID, "lg_debug_read(SIM): index/cols");
+      // the match itself never materialises the matrix: computed here, on demand, from the final projections of the last call
+      launch_lg_sim(lg->md.as<_Float16>(), lg->lens_c.as<int>(), LgDims{S, NP}, lg->sim.as<float>(), lg->stream);
+      SSHIP_HIP_CHECK(hipStreamSynchronize(lg->stream));
       SSHIP_HIP_CHECK(hipMemcpy2D(out, (size_t)cols * 4, lg->sim.as<float>() + (size_t)index * NP * NP, (size_t)NP * 4, (size_t)cols * 4, rows,
                                   hipMemcpyDeviceToHost));
       return SSHIP_OK;
@@ -1473,9 +1476,9 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
     SSHIP_HIP_CHECK(hipMemsetAsync(ms0, 0, (size_t)pairs * lg->max_kp * 4, s));
     return SSHIP_OK;
   }
-  launch_lg_sim(lg->md.as<_Float16>(), lens, d, lg->sim.as<float>(), s);
-  launch_lg_assign(lg->sim.as<float>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->max_kp, m0, ms0,
-                   0.1f /* filter_threshold */, s);
+  // log-assignment + mutual filter straight from md (lg_kernels.hip: k_assign_stream); lg->sim is the partials' scratch
+  launch_lg_assign(lg->md.as<_Float16>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->sim.as<float>(), lg->max_kp, m0, ms0,
+                   0.1f /* filter_threshold */, 0, s);
   SSHIP_HIP_CHECK(hipGetLastError());
   g_timer.mark("fe_lg_stereo_match:assign_filter", s);
   return SSHIP_OK;
@@ -1516,9 +1519,10 @@ extern "C" int sship_lg_bench_stage(sship_lg* lg, int stage, int iters, float* a
                             nullptr, nullptr, 0.f, nullptr, s); return hipGetLastError();
       case 5: launch_lg_ffn(w->ffn0_c[8], w->ffn3_c[8], w->ln_g_c[8], w->ln_b_c[8], ctx, x, d, &w->final_t, false, 0, 0, rope, q, k, vt,
                             lg->md.as<_Float16>(), w->match_w, w->match_b, lg->logsig.as<float>(), s); return hipGetLastError();
-      case 6: launch_lg_sim(lg->md.as<_Float16>(), lens, d, lg->sim.as<float>(), s); return hipGetLastError();
-      default: launch_lg_assign(lg->sim.as<float>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->max_kp, lg->m0.as<int32_t>(),
-                                lg->ms0.as<float>(), 0.1f, s); return hipGetLastError();
+      case 6: launch_lg_assign(lg->md.as<_Float16>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->sim.as<float>(), lg->max_kp,
+                               lg->m0.as<int32_t>(), lg->ms0.as<float>(), 0.1f, 1, s); return hipGetLastError();  // log-sum-exp pass
+      default: launch_lg_assign(lg->md.as<_Float16>(), lg->logsig.as<float>(), lens, d, lg->ws.as<float>(), lg->sim.as<float>(), lg->max_kp,
+                                lg->m0.as<int32_t>(), lg->ms0.as<float>(), 0.1f, 2, s); return hipGetLastError();  // arg-max pass
     }
   };
   // stages 3 / 4 update the residual stream in place: keep a copy and put it back (the values do not affect the timing, but

@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   // Software pipeline: the global loads of stage s+1 (weights; the input tile when a new 64-channel chunk
   // starts) are issued into registers BEFORE the MFMAs of stage s and written to LDS after them, so HBM/L2
   // latency hides under the matrix work instead of being exposed once per stage.
-  uint4 rin[IN_IT], rw[W_IT];
+  // (ext_vector registers, not HIP's uint4: that is a struct with unions, and an ARRAY of them stays in scratch memory -
+  // every instantiation of this kernel used 64-112 bytes of it per lane for these two prefetch arrays)
+  typedef unsigned q4_t __attribute__((ext_vector_type(4)));
+  q4_t rin[IN_IT], rw[W_IT];
   auto load_in = [&](int chunk) {
     const int c0 = chunk * 64;
     const _Float16* src;
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
       const int pix = u >> 3, part = u & 7;
       const int py = pix / TWH, px = pix - py * TWH;
       const int gy = y0 - HALO + py, gx = x0 - HALO + px;
-      uint4 v = make_uint4(0, 0, 0, 0);
+      q4_t v = {0u, 0u, 0u, 0u};
       if (u < IN_UNITS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-        v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * cs + part * 8);
+        v = *reinterpret_cast<const q4_t*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * cs + part * 8);
       rin[i] = v;
     }
   };
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int u = tid + i * 256;
-      if (u < IN_UNITS) *reinterpret_cast<uint4*>(s_in + (u >> 3) * kCP + (u & 7) * 8) = rin[i];
+      if (u < IN_UNITS) *reinterpret_cast<q4_t*>(s_in + (u >> 3) * kCP + (u & 7) * 8) = rin[i];
     }
   };
   auto load_w = [&](int stage) {
@@ -110,14 +113,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int u = tid + i * 256;
-      if (W_UNITS % 256 == 0 || u < W_UNITS) rw[i] = *reinterpret_cast<const uint4*>(wsrc + u * 8);
+      if (W_UNITS % 256 == 0 || u < W_UNITS) rw[i] = *reinterpret_cast<const q4_t*>(wsrc + u * 8);
     }
   };
   auto store_w = [&]() {
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int u = tid + i * 256;
-      if (W_UNITS % 256 == 0 || u < W_UNITS) *reinterpret_cast<uint4*>(s_w + u * 8) = rw[i];
+      if (W_UNITS % 256 == 0 || u < W_UNITS) *reinterpret_cast<q4_t*>(s_w + u * 8) = rw[i];
     }
   };
 

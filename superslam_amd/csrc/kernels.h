@@ -110,7 +110,7 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
                    _Float16* q, _Float16* k, _Float16* vt, _Float16* out, const float* match_w, float match_b,
                    float* logsig, hipStream_t s);
 void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s);
-void launch_lg_assign(const float* sim, const float* logsig, const int* lens, LgDims d, float* ws, int max_kp,
-                      int32_t* matches0, float* mscores0, float thr, hipStream_t s);
+void launch_lg_assign(const _Float16* md, const float* logsig, const int* lens, LgDims d, float* ws, float* pcol, int max_kp,
+                      int32_t* matches0, float* mscores0, float thr, int stage, hipStream_t s);
 
 }  // namespace sship

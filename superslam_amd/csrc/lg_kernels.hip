@@ -1456,15 +1456,256 @@ __global__ void k_assign_final(const int* __restrict__ lens, int NP, const float
   matches0[(size_t)pair * max_kp + i] = mj;
   mscores0[(size_t)pair * max_kp + i] = ms;
 }
-void launch_lg_assign(const float* sim, const float* logsig, const int* lens, LgDims d, float* ws, int max_kp,
-                      int32_t* matches0, float* mscores0, float thr, hipStream_t s) {
-  const int P = d.S / 2;
-  hipLaunchKernelGGL(k_assign_row_lse, dim3(d.NP / 4, P), dim3(256), 0, s, sim, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_col_lse, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_row_arg, dim3(d.NP / 4, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_col_arg, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, logsig, lens, d.NP, ws);
-  hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr,
-                     matches0, mscores0);
+// ---------------------------------------------------------------------------------------------------
+// Assignment without the similarity matrix (round 2): two streaming passes over md, each recomputing the 32 x 32 tiles of
+// sim = md0 md1^T on the matrix cores in BOTH orientations, so that every statistic is lane-local:
+//   acc_i = mfma(md1 tile, md0 tile): lane owns row i, its 16 registers are columns j  -> row statistics
+//   acc_j = mfma(md0 tile, md1 tile): lane owns column j, its 16 registers are rows i  -> column statistics
+// (the two orientations are the same products summed in the same k order: bit-identical values).
+// A wave owns a 32-row tile of image 0, keeps its md0 fragments in registers and walks the column tiles of image 1
+// (fragments streamed through a two-halves register ring).  PASS 0: online log-sum-exp per row (complete in the wave) and
+// per (row tile, column) partials; PASS 1: row arg-max of S_ij (complete) and per (row tile, column) partial arg-max.
+// k_assign_combine folds the NP / 32 column partials.  The fp32 [pairs][NP][NP] matrix (92 MB at 64 pairs, written once and
+// read four times: 0.22 ms) is never materialised; sship_lg_debug_read(SIM) computes it on demand with k_lg_sim.
+//   S_ij = (sim - lse_row_i) + (sim - lse_col_j) + ls0_i + ls1_j = 2 sim + c_i + d_j ; first index wins ties (torch.max).
+// The arg-max over j needs only 2 sim + d_j (c_i is added to the winner afterwards), the one over i only 2 sim + c_i:
+// one fma, one compare and two selects per entry.
+// ---------------------------------------------------------------------------------------------------
+// exp(x) for x <= 0 as v_exp_f32(x log2 e): two instructions (libm's expf is twelve, and these passes are instruction-bound);
+// relative error ~|x| 2^-24, far inside the assignment's tolerances (the scores are compared at 2e-2)
+constexpr float kLog2e = 1.44269504088896340736f;
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {  // (m, s) <- logsumexp-merge with (m2, s2)
+  const float M = fmaxf(m, m2);
+  const float a = m > -INFINITY ? s * fast_exp(m - M) : 0.f, b = m2 > -INFINITY ? s2 * fast_exp(m2 - M) : 0.f;
+  m = M; s = a + b;
+}
+// kAssignCh column chunks per row tile (blockIdx.z): 4x the waves (a wave per row tile alone leaves ~1 wave per SIMD with every
+// dependent-instruction stall exposed: 90 us per pass), at the price of per-chunk row partials next to the per-tile column ones
+constexpr int kAssignCh = 4;
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void k_assign_stream(const _Float16* __restrict__ md, const float* __restrict__ logsig,
+                                                       const int* __restrict__ lens, int NP, float* __restrict__ ws,
+                                                       float* __restrict__ pcol, float* __restrict__ prow) {
+  constexpr int kChunkCols = (kMaxKp / 32 + kAssignCh - 1) / kAssignCh * 32;  // columns of one chunk at most
+  __shared__ __attribute__((aligned(16))) float s_lc[PASS ? kChunkCols : 4];  // d_j = ls1_j - lse_col_j of this chunk's columns
+  const int pair = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jl = lane & 31, hh = lane >> 5;
+  const int NT = NP >> 5, ti = blockIdx.x * 4 + wave, i0 = ti * 32;
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
+  float* w = ws + (size_t)pair * 5 * NP;
+  if (blockIdx.x * 128 >= n0) return;          // no row of this workgroup exists (uniform: before any further barrier)
+  const bool active = ti < NT && i0 < n0;      // wave-uniform: a wave past the end still stages column tiles and joins the barriers
+  const _Float16* A = md + ((size_t)(2 * pair) * NP + min(i0 + jl, NP - 1)) * 256 + hh * 8;
+  const _Float16* Bm = md + (size_t)(2 * pair + 1) * NP * 256;
+  h8_t fa[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) fa[ks] = *reinterpret_cast<const h8_t*>(A + ks * 16);
+  const int my_i = i0 + jl;
+  const int ro = 4 * hh;  // register r of this lane <-> tile-local index (r & 3) + 8 (r >> 2) + ro
+  // PASS 1 inputs: lse_row / ls0 of the lane's own row, and of the 16 rows its acc_j registers stand for
+  float c_i = 0.f, c_r[PASS ? 16 : 1];  // c = ls0 - lse_row
+  if constexpr (PASS == 1) {
+    c_i = logsig[(size_t)(2 * pair) * NP + min(my_i, NP - 1)] - w[min(my_i, NP - 1)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = min(i0 + (r & 3) + 8 * (r >> 2) + ro, NP - 1);
+      c_r[r] = logsig[(size_t)(2 * pair) * NP + i] - w[i];
+    }
+  }
+  float rm = -INFINITY, rs = 0.f;  // PASS 0: running (max, sum) of the lane's row;  PASS 1: running best value (rm) ...
+  int rj = 0x7fffffff;             // ... and its column
+  const int ntj_all = (n1 + 31) >> 5, per = (ntj_all + kAssignCh - 1) / kAssignCh;
+  const int tj_lo = blockIdx.z * per, ntj = min(tj_lo + per, ntj_all);  // this workgroup's column tiles: [tj_lo, ntj)
+  if (tj_lo >= ntj) return;
+  const int jc0 = tj_lo * 32;  // first column of this chunk: s_lc / s_l1 are indexed by j - jc0
+  if constexpr (PASS == 1) {
+    for (int j = threadIdx.x; j < (ntj - tj_lo) * 32; j += 256)
+      s_lc[j] = logsig[(size_t)(2 * pair + 1) * NP + jc0 + j] - w[NP + jc0 + j];  // d_j = ls1_j - lse_col_j
+  }
+  // The four waves of the workgroup walk the same column tiles: a tile (32 rows x 512 B of image 1) is fetched ONCE, with
+  // coalesced loads (32 lanes = one row), into a padded LDS buffer (row stride 528 B: conflict-free ds_read_b128 fragments)
+  // - as fragments straight from global memory every load instruction touched 32 different rows (32 B each) and the
+  // texture path, not the matrix pipe, set the pace.  Two buffers; the next tile's loads are in flight during the MFMAs.
+  constexpr int kRowH = 264;  // halfs per LDS row
+  __shared__ __attribute__((aligned(16))) _Float16 s_b[2][32 * kRowH];
+  typedef unsigned stg_t __attribute__((ext_vector_type(4)));  // (HIP's uint4 is a struct with unions: an array of them lands in scratch)
+  stg_t stg[4];
+  auto fetch = [&](int tj) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = threadIdx.x + 256 * q, row = u >> 5, unit = u & 31;
+      stg[q] = *reinterpret_cast<const stg_t*>(Bm + (size_t)min(tj * 32 + row, NP - 1) * 256 + unit * 8);
+    }
+  };
+  auto put = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = threadIdx.x + 256 * q, row = u >> 5, unit = u & 31;
+      *reinterpret_cast<stg_t*>(&s_b[buf][row * kRowH + unit * 8]) = stg[q];
+    }
+  };
+  fetch(tj_lo);
+  put(0);
+  __syncthreads();
+  for (int tj = tj_lo; tj < ntj; ++tj) {
+    const int j0 = tj * 32, buf = (tj - tj_lo) & 1;
+    fetch(min(tj + 1, ntj - 1));  // unconditional (the last one re-reads this tile and is never used): keeps stg in registers
+    const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16x_t ai = zero16, aj = zero16;
+    if (active) {
+      const _Float16* bt = &s_b[buf][jl * kRowH + hh * 8];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const h8_t fbk = *reinterpret_cast<const h8_t*>(bt + k * 16);
+        ai = mfma32(fbk, fa[k], ai);
+        aj = mfma32(fa[k], fbk, aj);
+      }
+    }
+    put(buf ^ 1);  // the other buffer: its last readers passed the barrier at the end of the previous iteration
+    __syncthreads();
+    if (!active) continue;
+    const int my_j = j0 + jl;
+    // entries outside n0 x n1 become -inf; only the last row tile / column tile can have any (wave-uniform branches)
+    if (j0 + 32 > n1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (j0 + (r & 3) + 8 * (r >> 2) + ro >= n1) ai[r] = -INFINITY;
+      if (my_j >= n1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) aj[r] = -INFINITY;
+      }
+    }
+    if (i0 + 32 > n0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (i0 + (r & 3) + 8 * (r >> 2) + ro >= n0) aj[r] = -INFINITY;
+      if (my_i >= n0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ai[r] = -INFINITY;
+      }
+    }
+    if constexpr (PASS == 0) {
+      // ---- row: online log-sum-exp over this tile's 16 columns of the lane
+      float tm = ai[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ai[r]);
+      if (tm > -INFINITY) {
+        float ts = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ts += __builtin_amdgcn_exp2f(fmaf(ai[r], kLog2e, -tm * kLog2e));
+        lse_merge(rm, rs, tm, ts);
+      }
+      // ---- column partial over the 32 rows of this wave
+      float cm = aj[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) cm = fmaxf(cm, aj[r]);
+      float cs = 0.f;
+      if (cm > -INFINITY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs += __builtin_amdgcn_exp2f(fmaf(aj[r], kLog2e, -cm * kLog2e));
+      }
+      lse_merge(cm, cs, __shfl_xor(cm, 32, 64), __shfl_xor(cs, 32, 64));
+      if (hh == 0 && my_j < n1) *reinterpret_cast<float2*>(pcol + (((size_t)pair * NT + ti) * NP + my_j) * 2) = make_float2(cm, cs);
+    } else {
+      // ---- row: arg-max over this tile's 16 columns of the lane (ascending j inside the lane)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int jb = j0 + 8 * g + ro;
+        const float4 d4 = *reinterpret_cast<const float4*>(s_lc + jb - jc0);
+        const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(2.f, ai[4 * g + e], dv[e]);
+          if (v > rm) { rm = v; rj = jb + e; }  // masked entries are -inf: never greater
+        }
+      }
+      // ---- column partial arg-max over the 32 rows of this wave (ascending i inside the lane)
+      const float d_j = s_lc[my_j - jc0];
+      float cv = -INFINITY;
+      int ci = 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + (r & 3) + 8 * (r >> 2) + ro;
+        const float v = fmaf(2.f, aj[r], c_r[r]);
+        if (v > cv) { cv = v; ci = i; }
+      }
+      const float ov = __shfl_xor(cv, 32, 64);
+      const int oi = __shfl_xor(ci, 32, 64);
+      if (ov > cv || (ov == cv && oi < ci)) { cv = ov; ci = oi; }
+      if (hh == 0 && my_j < n1)
+        *reinterpret_cast<float2*>(pcol + (((size_t)pair * NT + ti) * NP + my_j) * 2) = make_float2(cv + d_j, __int_as_float(ci));
+    }
+  }
+  float2* pr = reinterpret_cast<float2*>(prow) + ((size_t)pair * kAssignCh + blockIdx.z) * NP + my_i;
+  if constexpr (PASS == 0) {
+    lse_merge(rm, rs, __shfl_xor(rm, 32, 64), __shfl_xor(rs, 32, 64));
+    if (hh == 0 && my_i < n0) *pr = make_float2(rm, rs);
+  } else {
+    const float ov = __shfl_xor(rm, 32, 64);
+    const int oj = __shfl_xor(rj, 32, 64);
+    if (ov > rm || (ov == rm && oj < rj)) { rm = ov; rj = oj; }
+    if (hh == 0 && my_i < n0) *pr = make_float2(rm + c_i, __int_as_float(rj));
+  }
+}
+// folds the partials: columns over the row tiles, rows over the column chunks.  PASS 0 -> lse_col / lse_row, PASS 1 -> arg-max
+// row of every column / arg-max column (and its score) of every row; ties: smaller index
+template <int PASS>
+__global__ __launch_bounds__(256) void k_assign_combine(const float* __restrict__ pcol, const float* __restrict__ prow,
+                                                        const int* __restrict__ lens, int NP, float* __restrict__ ws) {
+  const int pair = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;  // t < NP: column t, NP <= t < 2 NP: row t - NP
+  const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
+  const int NT = NP >> 5;
+  float* w = ws + (size_t)pair * 5 * NP;
+  const bool is_col = t < NP;
+  const int idx = is_col ? t : t - NP;
+  if (idx >= (is_col ? n1 : n0)) return;
+  const int ntj_all = (n1 + 31) >> 5, per = (ntj_all + kAssignCh - 1) / kAssignCh;
+  const int nparts = is_col ? (n0 + 31) >> 5 : (ntj_all + per - 1) / max(per, 1);  // row tiles that exist / chunks that got column tiles
+  const float2* p = reinterpret_cast<const float2*>(is_col ? pcol : prow) + (size_t)pair * (is_col ? NT : kAssignCh) * NP + idx;
+  if constexpr (PASS == 0) {
+    float m = -INFINITY, s = 0.f;
+    for (int k = 0; k < nparts; ++k) { const float2 v = p[(size_t)k * NP]; lse_merge(m, s, v.x, v.y); }
+    w[(is_col ? NP : 0) + idx] = m + logf(s);
+  } else {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = 0; k < nparts; ++k) {
+      const float2 v = p[(size_t)k * NP];
+      const int i = __float_as_int(v.y);
+      if (v.x > best || (v.x == best && i < bi)) { best = v.x; bi = i; }
+    }
+    // a row / column of NaN / -inf scores keeps index 0, like torch.max on a degenerate row (never an out-of-range index)
+    if (is_col) reinterpret_cast<int*>(w)[4 * NP + idx] = bi == 0x7fffffff ? 0 : bi;
+    else { w[2 * NP + idx] = best; reinterpret_cast<int*>(w)[3 * NP + idx] = bi == 0x7fffffff ? 0 : bi; }
+  }
+}
+
+// stage = 0: both passes + the mutual filter (a match call); 1 / 2: one pass only (sship_lg_bench_stage)
+void launch_lg_assign(const _Float16* md, const float* logsig, const int* lens, LgDims d, float* ws, float* pcol, int max_kp,
+                      int32_t* matches0, float* mscores0, float thr, int stage, hipStream_t s) {
+  const int P = d.S / 2, NT = d.NP / 32;
+  static const bool legacy = getenv("SUPERSLAM_HIP_LG_ASSIGN") && std::string(getenv("SUPERSLAM_HIP_LG_ASSIGN")) == "matrix";  // A/B
+  if (legacy && stage == 0) {  // the four passes over a materialised sim (sim lives in pcol's allocation: P * NP * NP floats)
+    float* sim = pcol;
+    launch_lg_sim(md, lens, d, sim, s);
+    hipLaunchKernelGGL(k_assign_row_lse, dim3(d.NP / 4, P), dim3(256), 0, s, sim, lens, d.NP, ws);
+    hipLaunchKernelGGL(k_assign_col_lse, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, lens, d.NP, ws);
+    hipLaunchKernelGGL(k_assign_row_arg, dim3(d.NP / 4, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
+    hipLaunchKernelGGL(k_assign_col_arg, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, logsig, lens, d.NP, ws);
+  } else {
+    float* prow = pcol + (size_t)P * NT * d.NP * 2;  // [P][kAssignCh][NP][2] behind the column partials [P][NT][NP][2]
+    if (stage == 0 || stage == 1) {
+      hipLaunchKernelGGL(k_assign_stream<0>, dim3((NT + 3) / 4, P, kAssignCh), dim3(256), 0, s, md, logsig, lens, d.NP, ws, pcol, prow);
+      hipLaunchKernelGGL(k_assign_combine<0>, dim3((2 * d.NP + 255) / 256, P), dim3(256), 0, s, pcol, prow, lens, d.NP, ws);
+    }
+    if (stage == 0 || stage == 2) {
+      hipLaunchKernelGGL(k_assign_stream<1>, dim3((NT + 3) / 4, P, kAssignCh), dim3(256), 0, s, md, logsig, lens, d.NP, ws, pcol, prow);
+      hipLaunchKernelGGL(k_assign_combine<1>, dim3((2 * d.NP + 255) / 256, P), dim3(256), 0, s, pcol, prow, lens, d.NP, ws);
+    }
+  }
+  if (stage == 0)
+    hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr,
+                       matches0, mscores0);
 }
 
 }  // namespace sship
