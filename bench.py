@@ -324,7 +324,8 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
         "lg_self_ffn+to_qk|to_v": 2.0 * S * n * (512 * 512 + 512 * 256 + 256 * 256 + 512 * 256),
         "lg_cross_ffn+wqkv": 2.0 * S * n * (512 * 512 + 512 * 256 + 256 * 256 + 768 * 256),
         "lg_last_ffn+final_proj": 2.0 * S * n * (512 * 512 + 512 * 256 + 256 * 256 + 256 * 256 + 256),
-        "lg_assign_sim": 2.0 * P * n * n * 256,
+        "lg_assign_pass1_lse": 2.0 * P * n * n * 256,   # sim tiles (algorithmic count: once) + row / column log-sum-exp
+        "lg_assign_pass2_argmax": 2.0 * P * n * n * 256,  # sim tiles again + row / column arg-max
     }
     lg_ms = {}
     for sid, name in enumerate(lg_flops):
@@ -359,7 +360,7 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     ms_nms, _ = sp_layer(12)
     hbm_entry("k_nms_tile (softmax + depth-to-space + 9x9 NMS + threshold + compaction)", ms_nms,
               B * (65 * Hc * Wc * 4 + n_cand_bytes), "fp32 logits [65,Hc,Wc] read once + ~7k candidates x 8 B written, per image",
-              B * (80 * Hc * Wc * 4 + n_cand_bytes))
+              B * (68 * Hc * Wc * 4 + n_cand_bytes))
     ms_pb = layer_ms["convPb"]
     hbm_entry("k_convpb_stream convPb (1x1, 256 -> 65, fp32 logits)", ms_pb, B * (256 * Hc * Wc * 2 + 65 * Hc * Wc * 4),
               "fp16 convPa map read + fp32 logits written, per image", B * (256 * Hc * Wc * 2 + 80 * Hc * Wc * 4))
@@ -370,10 +371,11 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     hbm_entry("k_desc_head_sparse (convDa + convDb at the keypoints + normalise x2 + gather)", ms_dh,
               B * (K * 9 * 128 * 2 + K * 256 * 2 + 8 * K), "9 x 256 B encoder rows per keypoint read + [N,256] fp16 written + 8N index bytes, "
               "per image (SURVEY 8(d) gather figure is the last two terms: N*256*2 read + write + 8N)")
-    ms_as = lg_stage(7)
-    hbm_entry("k_assign_* (row/col log-sum-exp, row/col arg-max, filter)", ms_as, P * (2 * n * n * 4 + 4 * n * 4),
-              "fp32 sim [n,n] read twice (one statistics pass, one arg-max pass is the algorithmic minimum) per pair",
-              P * (4 * n * n * 4))
+    ms_as = lg_stage(6) + lg_stage(7)
+    hbm_entry("k_assign_stream x2 + combine (log-sum-exp pass, arg-max pass; no sim matrix in memory)", ms_as,
+              P * (2 * 2 * n * 256 * 2 + 4 * n * 4),
+              "final projections of both images [n,256] fp16 read once per pass + match vectors, per pair (matrix-pipe / VALU bound)",
+              P * 2 * ((n + 31) // 32 + 4) * n * 256 * 2)
     out["roofline_hbm"] = hbm
 
     # ---- N = 1024 keypoints per image (the reference engine's upper profile; SURVEY 8(d) config 2 second run) ----

@@ -26,7 +26,7 @@ ds = torch.nn.functional.normalize(torch.randn((2 * P, K, 256), generator=g), di
 n = torch.full((2 * P,), K, dtype=torch.int32)
 lg.match_batch_device(kp.cuda(), n.cuda(), ds.cuda())
 torch.cuda.synchronize()
-names = ["wqkv0", "self_attn", "cross_attn", "self_ffn", "cross_ffn", "last_ffn", "sim", "assign"]
+names = ["wqkv0", "self_attn", "cross_attn", "self_ffn", "cross_ffn", "last_ffn", "assign_lse", "assign_arg"]
 out = []
 for sid, name in enumerate(names):
     ms = C.c_float(0)
