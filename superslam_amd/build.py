@@ -18,6 +18,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # of the conv epilogues paid for that.  None of these kernels produces or tests for a NaN (masked scores are -inf,
 # never inf - inf); infinities keep their meaning.
 FILE_FLAGS = {f: ["-fno-honor-nans"] for f in ("lg_kernels.hip", "conv_pp.hip", "conv_pp128.hip", "conv_strip.hip", "sp_convs.hip")}
+# LightGlue kernels: no packed-fp32 VALU (v_pk_mul_f32, v_pk_fma_f32, ...).  Two workgroups share a CU there so that one's
+# GELU / LayerNorm / softmax VALU rides next to the other's MFMA stream, and next to an MFMA stream a packed-fp32
+# instruction costs 17 clocks per wave-instruction against 6.4 for a plain one (profiles/r02_valu_rates_next_to_mfma.txt):
+# two scalar instructions beat one packed one.  -1 % on a 64-pair LightGlue call.
+FILE_FLAGS["lg_kernels.hip"] = FILE_FLAGS["lg_kernels.hip"] + ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _newest(paths):
