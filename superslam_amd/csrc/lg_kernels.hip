@@ -839,8 +839,10 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   float (*s_red)[NTOK] = reinterpret_cast<float (*)[NTOK]>(s_x + NTOK * kFfnLd);     // [8][NTOK]: per-wave sums, sums of squares
   float* s_par = reinterpret_cast<float*>(s_red) + 8 * NTOK;                         // [b0 512 | gamma 512 | beta 512 | b3 256]
   float* s_pb = s_par + 1792;                                                        // bias of the fused projection [<= 768]
+  float* s_b0b = s_pb + 768;  // second copy of b0: the accumulators of both N-tiles start from the bias, one ds_read each (no copies)
   for (int i = threadIdx.x; i < (PROJ ? 0 : 1792); i += 256)
     s_par[i] = i < 512 ? b0[i] : i < 1024 ? gamma[i - 512] : i < 1536 ? beta[i - 1024] : b3[i - 1536];
+  for (int i = threadIdx.x; i < (PROJ ? 0 : 512); i += 256) s_b0b[i] = b0[i];
   // LDS, not global: a global load in the epilogue sits behind the epilogue's own stores in the in-order vmcnt queue
   // (the first version of this kernel spent 16 k clocks per CrossBlock tile there)
   if constexpr (NEXT_MT > 0 && HEADS)
@@ -884,13 +886,18 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   stamp(0);
   if constexpr (!PROJ) {
   // ---- ffn.0 : rows [128 wave, +128) x 64 tokens, K = 512.  Fragment f = 2 * (64-row block) + m-tile ----
+  // the accumulators start from the ffn.0 bias (row 8 g + 4 hh + e of fragment f is register 4 g + e): 128 v_add_f32 per lane and
+  // tile less in the statistics phase, which - like GELU - runs at VALU issue rate next to the other workgroup's MFMAs
   f16x_t acc[4][NT];
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[f][n][r] = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>((n ? s_b0b + zero : b0q) + wave * 128 + f * 32 + hh * 4 + g * 8);
+        acc[f][n][4 * g + 0] = bv.x; acc[f][n][4 * g + 1] = bv.y; acc[f][n][4 * g + 2] = bv.z; acc[f][n][4 * g + 3] = bv.w;
+      }
   {
     // Weight fragments stream from L2 through a ring of R0 k-steps of registers: the load of k-step ks + R0 - 1 is issued
     // before the MFMAs of k-step ks, so every fragment has (R0 - 1) x 8 MFMAs (~1 k clocks) to arrive - an L2 hit under load
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
     }
   }
   stamp(1);
-  // ---- bias, LayerNorm(512) statistics (regs -> lane^32 -> the 4 waves through LDS) ----
+  // ---- LayerNorm(512) statistics (regs -> lane^32 -> the 4 waves through LDS); the bias is already in ----
   float sum[NT], sq[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { sum[n] = 0.f; sq[n] = 0.f; }
@@ -932,10 +939,8 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   for (int f = 0; f < 4; ++f)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 bv = *reinterpret_cast<const float4*>(b0q + wave * 128 + f * 32 + hh * 4 + g * 8);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        acc[f][n][4 * g + 0] += bv.x; acc[f][n][4 * g + 1] += bv.y; acc[f][n][4 * g + 2] += bv.z; acc[f][n][4 * g + 3] += bv.w;
         sum[n] += (acc[f][n][4 * g + 0] + acc[f][n][4 * g + 1]) + (acc[f][n][4 * g + 2] + acc[f][n][4 * g + 3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sq[n] = fmaf(acc[f][n][4 * g + e], acc[f][n][4 * g + e], sq[n]);
@@ -965,6 +970,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
     for (int w = 0; w < 4; ++w) { t += s_red[w][n * 32 + j]; q += s_red[4 + w][n * 32 + j]; }
     mean[n] = t * (1.0f / 512.0f);
     rstd[n] = __builtin_amdgcn_rsqf(fmaxf(q * (1.0f / 512.0f) - mean[n] * mean[n], 0.f) + 1e-5f);
+    mean[n] = -mean[n] * rstd[n];  // LayerNorm as two fmas per value: (a rstd - mean rstd) gamma + beta
   }
   stamp(2);
 #pragma unroll
@@ -978,8 +984,8 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const f2_t a01 = {acc[f][n][4 * g + 0], acc[f][n][4 * g + 1]}, a23 = {acc[f][n][4 * g + 2], acc[f][n][4 * g + 3]};
-        const f2_t o01 = gelu2((a01 - mean[n]) * rstd[n] * g01 + b01);
-        const f2_t o23 = gelu2((a23 - mean[n]) * rstd[n] * g23 + b23);
+        const f2_t o01 = gelu2((a01 * rstd[n] + mean[n]) * g01 + b01);
+        const f2_t o23 = gelu2((a23 * rstd[n] + mean[n]) * g23 + b23);
         *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o01[0], o01[1], o23[0], o23[1]);
       }
     }
@@ -1203,7 +1209,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
 }
 template <int NEXT_MT, bool HEADS, bool PROJ, typename... A>
 static hipError_t launch_ffn4(int tokens, hipStream_t s, A... args) {
-  constexpr size_t smem = (size_t)64 * kFfnLd * 2 + 8 * 64 * 4 + (1792 + 768) * 4;  // 78,848 B: two workgroups per CU
+  constexpr size_t smem = (size_t)64 * kFfnLd * 2 + 8 * 64 * 4 + (1792 + 768 + 512) * 4;  // 80,896 B: two workgroups per CU
   static_assert(2 * smem <= 163840, "two workgroups must fit the CU's LDS");
   auto kern = k_lg_ffn4<NEXT_MT, HEADS, PROJ>;
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
