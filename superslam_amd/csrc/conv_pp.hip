@@ -44,6 +44,10 @@
 #ifndef SSHIP_PP_NBUF
 #define SSHIP_PP_NBUF 3
 #endif
+// timing ablation (results are wrong): 1 = the MFMA loop reads its first fragments only and reuses them
+#ifndef SSHIP_PP_ABL
+#define SSHIP_PP_ABL 0
+#endif
 // accumulator initialisation (bias reads): 1 = at the end of the preceding data half-step, 0 = at the start of the MFMA half-step
 #ifndef SSHIP_PP_ACC_PRELOAD
 #define SSHIP_PP_ACC_PRELOAD 1
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     if constexpr (chunk == 0 && !SSHIP_PP_ACC_PRELOAD) acc_init();
 #pragma unroll
     for (int idx = 0; idx < 36; ++idx) {
-      if (idx + NBUF - 1 < 36) load_frags(idx + NBUF - 1, (idx + NBUF - 1) % NBUF);
+      if (idx + NBUF - 1 < 36 && !(SSHIP_PP_ABL & 1)) load_frags(idx + NBUF - 1, (idx + NBUF - 1) % NBUF);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < 2; ++n)
