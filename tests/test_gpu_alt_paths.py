@@ -135,6 +135,48 @@ def test_two_stream_lightglue_is_bit_identical_to_one_stream(weights_dir, tmp_pa
     print("two-stream LightGlue: 64 pairs,", int((outs[0]["m"] >= 0).sum()), "matches, identical")
 
 
+_DENSE_WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from superslam_amd import SuperPoint, _lib
+from superslam_amd.synth import make_frame
+_lib.init(0)
+out = {{}}
+for (h, w, b) in {shapes!r}:
+    sp = SuperPoint({sp_path!r}, 600, 0.005, 4, max_batch=b); assert sp.initialize(), sp.last_error
+    imgs = torch.from_numpy(np.stack([make_frame(h, w, 31 + i) for i in range(b)])).cuda()
+    scores, desc, logits = sp.dense(imgs, want_logits=True)
+    torch.cuda.synchronize()
+    out["l_%dx%d" % (h, w)] = logits.cpu().numpy(); out["d_%dx%d" % (h, w)] = desc.float().cpu().numpy()
+    sp.close()
+np.savez({out!r}, **out)
+"""
+# tile-count corner cases of the ping-pong conv kernels: one partial tile per layer (64 x 64: the conv4 maps are 8 x 8), a single
+# tile column, widths that are not multiples of 32 at any pyramid level, odd batch (tiles split unevenly between the wave groups)
+_DENSE_SHAPES = [(64, 64, 1), (72, 136, 3), (104, 520, 1), (376, 248, 2)]
+
+
+def test_conv_kernels_agree_on_tile_corner_cases(weights_dir, tmp_path):
+    """Dense logits / descriptor grids of the default conv kernels against the lock-step strip kernel (an independent
+    implementation with 64-bit addressing and per-unit masks) and against the 32-row-tile kernel, on image sizes chosen for
+    the staging corner cases of conv_pp.hip / conv_pp128.hip (affine buffer addressing, out-of-range zero fill, scalar tile
+    walk, uneven tile split between the two wave groups).  fp16 activations, different fp32 summation orders: logits
+    (O(25)) within 4e-2, unit-norm descriptor grid within 1e-2."""
+    res = {}
+    for name, env in (("default", {}), ("strip", {"SUPERSLAM_HIP_CONV": "strip"}), ("ct32", {"SUPERSLAM_HIP_CONV128": "ct32"})):
+        out = str(tmp_path / ("dense_" + name + ".npz"))
+        code = _DENSE_WORKER.format(root=ROOT, sp_path=weights_dir["sp_path"], shapes=_DENSE_SHAPES, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = np.load(out)
+    for (h, w, _) in _DENSE_SHAPES:
+        for alt in ("strip", "ct32"):
+            dl = np.abs(res["default"]["l_%dx%d" % (h, w)] - res[alt]["l_%dx%d" % (h, w)]).max()
+            dd = np.abs(res["default"]["d_%dx%d" % (h, w)] - res[alt]["d_%dx%d" % (h, w)]).max()
+            print(f"{h}x{w} default vs {alt}: logits max|d| {dl:.3e}, descriptor grid max|d| {dd:.3e}")
+            assert dl < 4e-2 and dd < 1e-2, (h, w, alt, dl, dd)
+
+
 def test_mfma_probe_reports_a_plausible_rate():
     import ctypes as C
 
