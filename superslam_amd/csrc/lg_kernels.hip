@@ -883,6 +883,18 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   auto stamp = [&](int slot) {
     if (tail.trace && it == 1 && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
   };
+  // Weight fragments are fetched with buffer loads: one lane-offset VGPR (lane * 16 B) for every load of the kernel, the
+  // fragment's position as a scalar offset.  With flat 64-bit pointers hipcc spent ~230 VALU instructions per tile on address
+  // arithmetic (v_lshl_add_u64, v_add_co / v_addc pairs), and this kernel runs at VALU issue rate (2.7 k VALU instructions
+  // against 448 MFMAs per wave and tile, two waves per SIMD).
+  typedef unsigned wq_t __attribute__((ext_vector_type(4)));
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto wres = [&](const _Float16* base) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, (int)0x7ffffff0, 0x00020000);
+  };
+  auto wload = [&](__amdgpu_buffer_rsrc_t r, int halfs) __attribute__((always_inline)) {  // fragment at base + halfs (+ lane * 8)
+    return __builtin_bit_cast(h8_t, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, halfs * 2 + zero, 0));
+  };
   stamp(0);
   if constexpr (!PROJ) {
   // ---- ffn.0 : rows [128 wave, +128) x 64 tokens, K = 512.  Fragment f = 2 * (64-row block) + m-tile ----
@@ -904,8 +916,9 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
     // takes 600-900 clocks, and the two-group scheme of k_lg_ffn (one group = 512 clocks of cover) left this kernel's MFMA
     // phases at half rate.  The token-tile B fragments are read from LDS one k-step ahead.
     constexpr int R0 = 4;
-    const _Float16* wp = w0q + (size_t)(2 * wave) * (32 * 2 * 512) + lane * 8;  // packed [cb = 2 wave + (f >> 1)][k16][mt = f & 1][lane][8]
-    auto frag = [&](int ks, int f) { return *reinterpret_cast<const h8_t*>(wp + (size_t)(f >> 1) * (32 * 2 * 512) + (ks * 2 + (f & 1)) * 512); };
+    const __amdgpu_buffer_rsrc_t r0 = wres(w0p);  // packed [cb = 2 wave + (f >> 1)][k16][mt = f & 1][lane][8]
+    const int w0off = (2 * wave) * (32 * 2 * 512);
+    auto frag = [&](int ks, int f) __attribute__((always_inline)) { return wload(r0, w0off + (f >> 1) * (32 * 2 * 512) + (ks * 2 + (f & 1)) * 512); };
     h8_t ab[R0][4], bf[2][NT];
 #pragma unroll
     for (int i = 0; i < R0 - 1; ++i)
@@ -1002,12 +1015,13 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
       for (int r = 0; r < 16; ++r) ac2[m][n][r] = 0.f;
   {
     constexpr int R3 = 8;
-    const _Float16* wp = w3q + (size_t)(2 * wave) * (32 * 512) + lane * 8;  // packed [cb = 2 wave + m][k16][mt = 0][lane][8]
+    const __amdgpu_buffer_rsrc_t r3 = wres(w3p);  // packed [cb = 2 wave + m][k16][mt = 0][lane][8]
+    const int w3off = (2 * wave) * (32 * 512);
     h8_t a3[R3][2], bf[2][NT];
 #pragma unroll
     for (int i = 0; i < R3 - 1; ++i)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) a3[i][m] = *reinterpret_cast<const h8_t*>(wp + (size_t)m * (32 * 512) + i * 512);
+      for (int m = 0; m < 2; ++m) a3[i][m] = wload(r3, w3off + m * (32 * 512) + i * 512);
 #pragma unroll
     for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd);
 #pragma unroll
@@ -1015,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
       if (ks + R3 - 1 < 32) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          a3[(ks + R3 - 1) % R3][m] = *reinterpret_cast<const h8_t*>(wp + (size_t)m * (32 * 512) + (ks + R3 - 1) * 512);
+          a3[(ks + R3 - 1) % R3][m] = wload(r3, w3off + m * (32 * 512) + (ks + R3 - 1) * 512);
       }
       if (ks + 1 < 32) {
 #pragma unroll
@@ -1087,21 +1101,22 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
               cs[g][n] = *reinterpret_cast<const float4*>(pj.aux + (t0 + n * 32 + j) * 64 + ((cb * 32) & 63) + hh * 4 + g * 8);
         }
       }
-      const _Float16* wp = pj.wpack + (size_t)cb * (16 * NEXT_MT * 512) + lane * 8;  // [cb][k16][mt][lane][8]
+      const __amdgpu_buffer_rsrc_t rp = wres(tail.proj.wpack);  // [cb][k16][mt][lane][8]
+      const int wpoff = cb * (16 * NEXT_MT * 512);
       constexpr int VMASK = HEADS ? (1 << (NEXT_MT - 1)) : 0;  // the V tile runs with swapped operands (see k_lg_ffn)
       constexpr int RT = NEXT_MT >= 3 ? 4 : 5;
       h8_t at[RT][NEXT_MT], bf[2][NT];
 #pragma unroll
       for (int i = 0; i < RT - 1; ++i)
 #pragma unroll
-        for (int m = 0; m < NEXT_MT; ++m) at[i][m] = *reinterpret_cast<const h8_t*>(wp + (i * NEXT_MT + m) * 512);
+        for (int m = 0; m < NEXT_MT; ++m) at[i][m] = wload(rp, wpoff + (i * NEXT_MT + m) * 512);
 #pragma unroll
       for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (ks + RT - 1 < 16) {
 #pragma unroll
-          for (int m = 0; m < NEXT_MT; ++m) at[(ks + RT - 1) % RT][m] = *reinterpret_cast<const h8_t*>(wp + ((ks + RT - 1) * NEXT_MT + m) * 512);
+          for (int m = 0; m < NEXT_MT; ++m) at[(ks + RT - 1) % RT][m] = wload(rp, wpoff + ((ks + RT - 1) * NEXT_MT + m) * 512);
         }
         if (ks + 1 < 16) {
 #pragma unroll
