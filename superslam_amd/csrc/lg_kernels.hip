@@ -828,6 +828,12 @@ static hipError_t launch_ffn(int nt, int tokens, hipStream_t s, A... args) {
 //   * the residual operand is read from the x half of the LDS tile before it is overwritten (no global re-read);
 //   * the next tile's LDS-DMA is issued after the last epilogue: its latency is covered by the other workgroup.
 // ---------------------------------------------------------------------------------------------------
+// epilogue stores as buffer stores: 1 = x, 2 = V^T, 4 = q / k.  The V^T variant (2) produces wrong matches on the GPU although its
+// ISA reads correctly (bisected with this switch; not understood - suspect the same soffset handling in hipcc 7.2 that the empty
+// asm in wstore works around), so V^T keeps its flat stores: 4 of the 27 stores of a tile.
+#ifndef SSHIP_FFN4_BSTORE
+#define SSHIP_FFN4_BSTORE 5
+#endif
 template <int NEXT_MT, bool HEADS, bool PROJ>
 __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                     const float* __restrict__ b0, const float* __restrict__ gamma,
@@ -895,6 +901,18 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   auto wload = [&](__amdgpu_buffer_rsrc_t r, int halfs) __attribute__((always_inline)) {  // fragment at base + halfs (+ lane * 8)
     return __builtin_bit_cast(h8_t, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, halfs * 2 + zero, 0));
   };
+  // the epilogue's 16-byte stores the same way: lane offset in one VGPR, everything else scalar (q / k / V^T tiles are in fragment
+  // order, lane * 16 B again; x rows: token j -> j * 512 B + 16 hh)
+  // (the scalar offset goes through an empty asm: hipcc 7.2 otherwise gives raw buffer STORES whose soffsets differ by a constant
+  // the same soffset register and drops the constant - two stores land on one address; loads are not affected)
+  auto wstore = [&](__amdgpu_buffer_rsrc_t r, unsigned voff, long long halfs, wq_t v) __attribute__((always_inline)) {
+    int so = (int)(halfs * 2);
+    asm volatile("" : "+s"(so));
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, so, 0);
+  };
+  const unsigned xrow16 = (unsigned)j * 512u + (unsigned)hh * 16u;
+  const __amdgpu_buffer_rsrc_t rx = wres(x), rq = wres(static_cast<const _Float16*>(tail.proj.out0)),
+                               rk = wres(static_cast<const _Float16*>(tail.proj.out1)), rv = wres(static_cast<const _Float16*>(tail.proj.out2));
   stamp(0);
   if constexpr (!PROJ) {
   // ---- ffn.0 : rows [128 wave, +128) x 64 tokens, K = 512.  Fragment f = 2 * (64-row block) + m-tile ----
@@ -1066,7 +1084,8 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
         const auto s1 = __builtin_amdgcn_permlane32_swap(hi[2 * gp], hi[2 * gp + 1], false, false);
         const uint4 unit = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         const int c = wave * 64 + m * 32 + (2 * gp + hh) * 8;
-        *reinterpret_cast<uint4*>(x + (t0 + n * 32 + j) * 256 + c) = unit;
+        if (SSHIP_FFN4_BSTORE & 1) wstore(rx, xrow16, (long long)(t0 + n * 32) * 256 + wave * 64 + m * 32 + 2 * gp * 8, wq_t{s0[0], s1[0], s0[1], s1[1]});
+        else *reinterpret_cast<uint4*>(x + (t0 + n * 32 + j) * 256 + c) = unit;
         if constexpr (NEXT_MT > 0) *reinterpret_cast<uint4*>(s_x + (n * 32 + j) * kFfnLd + c) = unit;
       }
     }
@@ -1146,26 +1165,27 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
             for (int n = 0; n < NT; ++n) {
               const size_t token = t0 + n * 32;
               const int sq = (int)(token / NP), kt = (int)(token - (size_t)sq * NP) >> 5;
-              _Float16* dst = static_cast<_Float16*>(pj.out2) + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048 + lane * 8;
+              const long long dst = (((long long)sq * 4 + hd) * nt32 + kt) * 2048;
 #pragma unroll
               for (int kk = 0; kk < 2; ++kk) {
                 h8_t o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (_Float16)(ac3[m][n][8 * kk + e] + bv);
-                *reinterpret_cast<h8_t*>(dst + (kk * 2 + mth) * 512) = o;
+                if (SSHIP_FFN4_BSTORE & 2) wstore(rv, lane16, dst + (kk * 2 + mth) * 512, __builtin_bit_cast(wq_t, o));
+                else *reinterpret_cast<h8_t*>(static_cast<_Float16*>(pj.out2) + dst + lane * 8 + (kk * 2 + mth) * 512) = o;
               }
             }
           } else {
             // q / k (or the shared qk of CrossBlock): bias, rotary on interleaved pairs, fp16, then lane^32 pairing so that
             // every lane owns whole 16-byte fragment units: unit u = d / 8 -> [kstep u / 2][lane' = (u & 1) * 32 + token % 32][8]
             const int seg = R0 >> 8;
-            _Float16* base = static_cast<_Float16*>(seg == 0 ? pj.out0 : pj.out1);
+            const __amdgpu_buffer_rsrc_t rqk = seg == 0 ? rq : rk;
             const bool roped = seg < rope_segs;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
               const size_t token = t0 + n * 32;
               const int sq = (int)(token / NP), kt = (int)(token - (size_t)sq * NP) >> 5;
-              _Float16* dst = base + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048;
+              const long long dst = (((long long)sq * 4 + hd) * nt32 + kt) * 2048;
               unsigned lo[4], hi[4];
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
@@ -1188,9 +1208,12 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
                 // B = quad 2 gp + 1, lane hh = 0 ends up with the whole unit of quad 2 gp, lane hh = 1 with that of 2 gp + 1.
                 const auto s0 = __builtin_amdgcn_permlane32_swap(lo[2 * gp], lo[2 * gp + 1], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(hi[2 * gp], hi[2 * gp + 1], false, false);
-                const uint4 unit = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                const int u = ((R0 & 63) >> 3) + 2 * gp + hh;
-                *reinterpret_cast<uint4*>(dst + (u >> 1) * 512 + (((u & 1) << 5) + j) * 8) = unit;
+                // unit u = ((R0 & 63) >> 3) + 2 gp + hh: (R0 & 63) >> 3 is 0 or 4, so u >> 1 is scalar and (u & 1) * 32 + j is the lane id
+                if (SSHIP_FFN4_BSTORE & 4) wstore(rqk, lane16, dst + ((((R0 & 63) >> 3) + 2 * gp) >> 1) * 512, wq_t{s0[0], s1[0], s0[1], s1[1]});
+                else {
+                  const int u = ((R0 & 63) >> 3) + 2 * gp + hh;
+                  *reinterpret_cast<uint4*>(static_cast<_Float16*>(seg == 0 ? pj.out0 : pj.out1) + dst + (u >> 1) * 512 + (((u & 1) << 5) + j) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
               }
             }
           }
