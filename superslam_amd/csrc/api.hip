@@ -1419,7 +1419,7 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   static const bool igemm_qkv0 = getenv("SUPERSLAM_HIP_LG_QKV0") && std::string(getenv("SUPERSLAM_HIP_LG_QKV0")) == "igemm";  // A/B
   const int n_layers = lg->debug_layers;  // kLgLayers except under sship_lg_debug_set_layers (test-only)
   // the layer stack of pairs [p0, p0 + np) on stream st: every buffer is sequence-major, pairs are independent
-  auto layers = [&](int p0, int np, hipStream_t st) -> int {
+  auto layers = [&](int p0, int np, hipStream_t st, bool shared_gpu) -> int {
     const LgDims ds{2 * np, lg->NP};
     const size_t tok = (size_t)2 * p0 * lg->NP;
     _Float16 *xs = x + tok * 256, *qs = q + tok * 256, *ks = k + tok * 256, *vs = vt + tok * 256, *cs = ctx + tok * 256;
@@ -1429,12 +1429,12 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
     else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st));
     for (int i = 0; i < n_layers; ++i) {
       // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
-      launch_lg_attention(qs, ks, vs, ls, ds, false, cs, st);
+      launch_lg_attention(qs, ks, vs, ls, ds, false, cs, st, shared_gpu);
       launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], cs, xs, ds, &w->cqkv_t[i], true, /*rope_segs=*/0,
                     /*t_seg=*/1, rs, qs, ks, vs, nullptr, nullptr, 0.f, nullptr, st);
       // CrossBlock (qk shared by both directions; sequence s attends to s^1); its FFN emits the next layer's Wqkv,
       // or final_proj + matchability after the last layer
-      launch_lg_attention(qs, qs, vs, ls, ds, true, cs, st);
+      launch_lg_attention(qs, qs, vs, ls, ds, true, cs, st, shared_gpu);
       if (i + 1 < kLgLayers)
         launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], cs, xs, ds, &w->qkv_t[i + 1], true, 2, 2, rs, qs, ks,
                       vs, nullptr, nullptr, 0.f, nullptr, st);
@@ -1460,14 +1460,14 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
     for (int i = 1; i < parts; ++i) {
       const int np = i + 1 < parts ? pairs / parts : pairs - p0;
       SSHIP_HIP_CHECK(hipStreamWaitEvent(lg->aux[i - 1], lg->ev_fork, 0));
-      if (int rc = layers(p0, np, lg->aux[i - 1])) return rc;
+      if (int rc = layers(p0, np, lg->aux[i - 1], true)) return rc;
       SSHIP_HIP_CHECK(hipEventRecord(lg->ev_join[i - 1], lg->aux[i - 1]));
       p0 += np;
     }
-    if (int rc = layers(0, pairs / parts, s)) return rc;
+    if (int rc = layers(0, pairs / parts, s, true)) return rc;
     for (int i = 1; i < parts; ++i) SSHIP_HIP_CHECK(hipStreamWaitEvent(s, lg->ev_join[i - 1], 0));
   } else {
-    if (int rc = layers(0, pairs, s)) return rc;
+    if (int rc = layers(0, pairs, s, false)) return rc;
   }
   SSHIP_HIP_CHECK(hipGetLastError());
   g_timer.mark("fe_lg_stereo_match:layers_x9", s);

@@ -102,7 +102,7 @@ void launch_lg_prep(const float* kp, int kp_stride, int kp_seq_stride, const int
 hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope_segs, int t_seg,
                            const float* rope, _Float16* q, _Float16* k, _Float16* vt, hipStream_t s);
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,
-                         bool cross, _Float16* ctx, hipStream_t s);
+                         bool cross, _Float16* ctx, hipStream_t s, bool shared_gpu = false);
 hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int rope_segs, int t_seg, const float* rope, _Float16* q,
                                 _Float16* k, _Float16* vt, hipStream_t s);
 void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,

@@ -355,14 +355,17 @@ static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt
   }
 }
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
-                         _Float16* ctx, hipStream_t s) {
+                         _Float16* ctx, hipStream_t s, bool shared_gpu) {
   // throughput batches: two query tiles per wave (half the K/V fragment traffic) and a 2-way key split; a few pairs only:
   // one tile per wave, 4-way key split, so the launch still has enough workgroups to cover the CUs (latency mode).
   // SUPERSLAM_HIP_ATTN_KS=4 keeps the 4-way split for throughput batches (A/B runs).
   static const int ks_env = getenv("SUPERSLAM_HIP_ATTN_KS") ? atoi(getenv("SUPERSLAM_HIP_ATTN_KS")) : 0;
   if (d.S * (d.NP / 64) * 4 >= 2 * cu_count()) {
+    // shared_gpu: another stream runs the other half-batch's kernels next to this launch (lg_forward), so the partly filled last
+    // round of a 256-query workgroup (no key split: no LDS merge, the prologue paid once per 19 key tiles) costs nothing:
+    // 92 -> 101 us for a launch on its own, but -1.2 % on the two-stream LightGlue call
     if (ks_env == 4) launch_attn<2, 4>(q, k, vt, lens, d, cross, ctx, s);
-    else if (ks_env == 1) launch_attn<2, 1>(q, k, vt, lens, d, cross, ctx, s);
+    else if (ks_env == 1 || (ks_env == 0 && shared_gpu)) launch_attn<2, 1>(q, k, vt, lens, d, cross, ctx, s);
     else launch_attn<2, 2>(q, k, vt, lens, d, cross, ctx, s);
   } else {
     launch_attn<1, 4>(q, k, vt, lens, d, cross, ctx, s);
