@@ -147,6 +147,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   // afterwards.  The buffer is rebuilt per tile on the image (base one row and one pixel before it), offsets stay 32-bit.
   typedef unsigned u4_t __attribute__((ext_vector_type(4)));
   constexpr unsigned P_OOB = 0xfffffff0u;
+  // epilogue: byte offset of this lane's output pixel column inside a tile row (pooled: even columns store, odd ones are dropped)
+  const unsigned ep_voff = POOL ? ((j & 1) ? P_OOB : (unsigned)(((j >> 1) * p.cout + hh * 8) * 2)) : (unsigned)((j * p.cout + hh * 8) * 2);
   constexpr int P_ROW_UNITS = P_TWH * 8;  // 272
   u4_t rin[FUSE1A ? 1 : 11];
   const int m_px = gt >> 3, m_part = gt & 7;                                   // main part: unit gt of a halo row
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   auto epilogue = [&](int u_lo, int u_hi) __attribute__((always_inline)) {
     const int y0 = ew.ty * P_TH, x0 = ew.tx * P_TW, b = ew.b;
     if (u_hi == 2 * MT) walk_next(ew);
-    const int yb = y0 + gw * 2, x = x0 + j;
+    const int yb = y0 + __builtin_amdgcn_readfirstlane(gw) * 2;  // wave-uniform, and the compiler must know it (scalar store offsets)
     const h2_t z2 = {(_Float16)0.f, (_Float16)0.f};
     auto relu2 = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {  // two values -> packed fp16, ReLU on the pair
       h2_t v = {(_Float16)lo, (_Float16)hi};
@@ -391,13 +393,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       const h2_t v = {(_Float16)lo, (_Float16)hi};
       return *reinterpret_cast<const unsigned*>(&v);
     };
-    // lanes hh = 0 / 1 hold channels 4 hh .. + 3 of an 8-channel unit: permlane32_swap pairs them into one 16-byte store each
-    auto store_pair = [&](_Float16* pix, int m, int g, unsigned a0, unsigned a1, unsigned b0, unsigned b1, bool ok) __attribute__((always_inline)) {
+    // lanes hh = 0 / 1 hold channels 4 hh .. + 3 of an 8-channel unit: permlane32_swap pairs them into one 16-byte store each.
+    // Buffer stores on the output image of this tile: the lane's pixel column is a tile-invariant VGPR offset (ep_voff; lanes
+    // that do not store - odd columns of the pooled variant, columns past the right edge - get an out-of-range offset and the
+    // store is dropped), everything else is a scalar offset.  No 64-bit address arithmetic, no exec masking in this role.
+    // (scalar offset through an empty asm: see wstore in lg_kernels.hip)
+    const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.out) + (size_t)b * Ho * Wo * p.cout * 2, 0, (int)0x7ffffff0, 0x00020000);
+    const int xo0 = POOL ? x0 >> 1 : x0;                       // first output column of the tile
+    unsigned voff = ep_voff;
+    if (xo0 + (POOL ? P_TW / 2 : P_TW) > Wo)                    // right-edge tile (wave-uniform): mask the columns past the image
+      voff = (xo0 + (POOL ? j >> 1 : j)) < Wo ? ep_voff : P_OOB;
+    auto store_pair = [&](int row_off, int m, int g, unsigned a0, unsigned a1, unsigned b0, unsigned b1) __attribute__((always_inline)) {
       const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
       const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-      if (ok) *reinterpret_cast<uint4*>(pix + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      int so = (row_off + cb * CT + m * 32 + g * 8) * 2;
+      asm volatile("" : "+s"(so));
+      typedef unsigned st4_t __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128(st4_t{r0[0], r1[0], r0[1], r1[1]}, ro, voff, so, 0);
     };
     if constexpr (!POOL) {
+      // (flat stores here: measured on one box, the buffer-store form gains 2 % on the pooled layers and loses 1-5 % on these)
+      const int x = x0 + j;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const int y = yb + n;
@@ -409,15 +427,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
           for (int g = 0; g < 4; g += 2) {
             if (2 * m + g / 2 < u_lo || 2 * m + g / 2 >= u_hi) continue;
             const f16x_t& a = acc[m][n];
-            store_pair(pix, m, g, relu2(a[4 * g + 0], a[4 * g + 1]), relu2(a[4 * g + 2], a[4 * g + 3]),
-                       relu2(a[4 * g + 4], a[4 * g + 5]), relu2(a[4 * g + 6], a[4 * g + 7]), ok);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(relu2(a[4 * g + 0], a[4 * g + 1]), relu2(a[4 * g + 4], a[4 * g + 5]), false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(relu2(a[4 * g + 2], a[4 * g + 3]), relu2(a[4 * g + 6], a[4 * g + 7]), false, false);
+            if (ok) *reinterpret_cast<uint4*>(pix + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
           }
       }
     } else {
-      const int Ho = p.H >> 1, Wo = p.W >> 1;
-      const int yo = yb >> 1, xo = x >> 1;
-      const bool ok = !(x & 1) && yo < Ho && xo < Wo;
-      _Float16* pix = p.out + ((size_t)(b * Ho + yo) * Wo + xo) * p.cout + cb * CT;
+      const int yo = yb >> 1;
+      if (yo >= Ho) voff = P_OOB;  // wave-uniform (the pooling arithmetic below still runs: DPP needs every lane)
+      const int pix = (yo * Wo + xo0) * p.cout;
       auto pool1 = [&](int m, int r) __attribute__((always_inline)) -> float {  // max over the wave's two rows and 0 (v_max3), then the column pair (dpp)
         const float tt = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), 0.f);
         const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tt), 0xB1, 0xF, 0xF, false));
@@ -429,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
         for (int g = 0; g < 4; g += 2) {
           if (2 * m + g / 2 < u_lo || 2 * m + g / 2 >= u_hi) continue;
           store_pair(pix, m, g, pack2(pool1(m, 4 * g + 0), pool1(m, 4 * g + 1)), pack2(pool1(m, 4 * g + 2), pool1(m, 4 * g + 3)),
-                     pack2(pool1(m, 4 * g + 4), pool1(m, 4 * g + 5)), pack2(pool1(m, 4 * g + 6), pool1(m, 4 * g + 7)), ok);
+                     pack2(pool1(m, 4 * g + 4), pool1(m, 4 * g + 5)), pack2(pool1(m, 4 * g + 6), pool1(m, 4 * g + 7)));
         }
     }
   };
