@@ -1540,7 +1540,7 @@ __global__ __launch_bounds__(256, 2) void k_assign_stream(const _Float16* __rest
   const int NT = NP >> 5, ti = blockIdx.x * 4 + wave, i0 = ti * 32;
   const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   float* w = ws + (size_t)pair * 5 * NP;
-  if (blockIdx.x * 128 >= n0) return;          // no row of this workgroup exists (uniform: before any further barrier)
+  if ((int)blockIdx.x * 128 >= n0) return;     // no row of this workgroup exists (uniform: before any further barrier)
   const bool active = ti < NT && i0 < n0;      // wave-uniform: a wave past the end still stages column tiles and joins the barriers
   const _Float16* A = md + ((size_t)(2 * pair) * NP + min(i0 + jl, NP - 1)) * 256 + hh * 8;
   const _Float16* Bm = md + (size_t)(2 * pair + 1) * NP * 256;
