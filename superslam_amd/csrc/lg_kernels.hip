@@ -856,16 +856,21 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   // (the first version of this kernel spent 16 k clocks per CrossBlock tile there)
   if constexpr (NEXT_MT > 0 && HEADS)
     for (int i = threadIdx.x; i < NEXT_MT * 256; i += 256) s_pb[i] = tail.proj.bias[i];
+  // token rows wave, wave + 4, ... of the tile: the lane's source address is formed once and advanced by 4 KiB per PAIR of rows
+  // (the odd row of a pair rides on the instruction offset, which applies to the global and the LDS address alike - M0 is set
+  // 2 KiB low for it): 8 address updates per tile instead of 16 selects + 64-bit adds in a kernel that runs at VALU issue rate
   auto stage_tile = [&](int tile, int wave, int lane) {
     const size_t tt = (size_t)tile * NTOK;
+    const char* gsrc = reinterpret_cast<const char*>((lane < 32 ? x + lane * 8 : ctx + (lane - 32) * 8) + (tt + wave) * 256);
 #pragma unroll
-    for (int k = 0; k < NTOK / 4; ++k) {
-      const int tok = wave + 4 * k;
-      const _Float16* gsrc = (lane < 32 ? x + (tt + tok) * 256 + lane * 8 : ctx + (tt + tok) * 256 + (lane - 32) * 8);
-      const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(s_x + tok * kFfnLd));
+    for (int k = 0; k < NTOK / 4; k += 2) {
+      const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(s_x + (wave + 4 * k) * kFfnLd));
+      const unsigned lds1 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(s_x + (wave + 4 * k + 4) * kFfnLd)) - 2048u;
       unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                   "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds0), "s"(lds1) : "memory");
+      gsrc += 4096;
     }
   };
   const int tile0 = blockIdx.x;
@@ -1114,13 +1119,15 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
       // rotary (cos, sin) quads of this lane's q / k rows: requested here, consumed after the MFMA loop.  The q and the k
       // tile of a block cover the same head-local channels ((8 m + cb) * 32 mod 64 does not depend on m): one set serves both.
       float4 cs[4][NT];
+      const __amdgpu_buffer_rsrc_t rrope = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tail.proj.aux), 0, (int)0x7ffffff0, 0x00020000);
       if constexpr (HEADS) {
         if (rope_segs > 0) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-              cs[g][n] = *reinterpret_cast<const float4*>(pj.aux + (t0 + n * 32 + j) * 64 + ((cb * 32) & 63) + hh * 4 + g * 8);
+              cs[g][n] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                  rrope, (unsigned)j * 256u + (unsigned)hh * 16u, (int)(((t0 + n * 32) * 64 + ((cb * 32) & 63) + g * 8) * 4) + zero, 0));
         }
       }
       const __amdgpu_buffer_rsrc_t rp = wres(tail.proj.wpack);  // [cb][k16][mt][lane][8]
