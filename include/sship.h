@@ -13,7 +13,12 @@
  *   - `stream` is a hipStream_t passed as void*; NULL is the legacy default stream itself (= torch's default
  *     stream), so consecutive asynchronous calls made with NULL - extractor then matcher - are ordered with each
  *     other and with the caller's default-stream work.  The synchronous host-image / host-keypoint entry points
- *     use the handle's own (blocking) stream and return after synchronising it;
+ *     use the handle's own (blocking) stream and return after synchronising it.  Multi-threaded callers: the legacy
+ *     default stream synchronises with EVERY blocking stream of the process, i.e. a NULL-stream batch call on one
+ *     thread serialises with another thread's handles (the loop-closure matcher / EigenPlaces).  The handle streams
+ *     do not synchronise with each other, so threads that use the synchronous entry points (the reference's usage)
+ *     run concurrently; a thread that drives the asynchronous batch API next to them should pass its own
+ *     hipStreamNonBlocking stream (or hipStreamPerThread) instead of NULL;
  *   - external dtypes follow the reference engines (scripts/rebuild_engines.sh:85-92,108-115):
  *     image u8 (normalised to [0,1] on device), scores f32, descriptors f16, kpts f32,
  *     matches0 i32, mscores0 f32.  Internal accumulation is f32.
@@ -208,8 +213,8 @@ int sship_lg_match_batch_device(sship_lg* lg, const float* kp_dev, const int* n_
                                 int pairs, int32_t* matches0_dev, float* mscores0_dev, void* stream);
 /* Test-only introspection of the matcher (no reference counterpart; used by the parity suite to compare the internals
  * with the oracle layer by layer - the product never calls these).
- * sship_lg_debug_set_layers: the next match calls on this handle run only the first n_layers (1..9) transformer layers and
- *   skip the assignment (matches0 = -1, mscores0 = 0); 9 restores the full matcher.
+ * sship_lg_debug_set_layers: the NEXT match call on this handle (one-shot) runs only the first n_layers (1..9) transformer
+ *   layers and skips the assignment (matches0 = -1, mscores0 = 0); the call after it is a full match again.
  * sship_lg_debug_read: after a match call, copy state of this handle to the host as f32 (device-synchronising):
  *   SSHIP_LG_DEBUG_X    residual stream of sequence `index` (2p = set 0, 2p+1 = set 1 of pair p): out[rows][256]
  *   SSHIP_LG_DEBUG_SIM  assignment similarity md0 md1^T of pair `index`: out[rows][cols]
@@ -255,12 +260,14 @@ int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs_
                                 int32_t* matches0_dev, float* mscores0_dev, void* stream);
 
 /* Per-stage device timings (ms) of the calling thread's last call sequence made with profiling enabled
- * (sship_set_profiling(1) inserts hipEvents; off by default).  Labels are "<scope>:<stage>" where <scope> is the
+ * (sship_set_profiling(1) inserts hipEvents; off by default; level 2 adds one event per SuperPoint layer launch - labels
+ * "<scope>:<stage>/<layer>", e.g. "sp_gpu_infer:encoder/conv1a+conv1b+pool" - the IN-SITU launch durations bench.py's roofline
+ * line reports; a profiled batch call also keeps a device copy of its input so that sship_sp_bench_layer re-launches on real pixels).  Labels are "<scope>:<stage>" where <scope> is the
  * reference's own SUPERSLAM_PROFILE label the stage belongs to - sp_gpu_infer (src/SuperPoint.cc:639),
  * sp_extract_stereo (:904), fe_lg_stereo_match (src/StereoFrontEnd.cc:32) - and <stage> this library's finer split
  * (encoder, heads, select, gather, posenc_qkv0, layers_x9, assign_filter); summing a scope's stages gives the
  * reference's figure.  Timers are per thread.  Returns the number of stages. */
-void sship_set_profiling(int on);
+void sship_set_profiling(int level);
 int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
 
 /* Measurement hook for bench.py's roofline line: re-launch ONE layer of the network `iters` times on the

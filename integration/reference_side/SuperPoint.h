@@ -34,6 +34,24 @@ inline superslam::DeviceDescriptors to_ref(const superslam_hip::DeviceDescriptor
   o.data = d.data; o.count = d.count; o.dim = d.dim; o.slot = d.slot; o.slot_ref = d.slot_ref;
   return o;
 }
+// The reference's SUPERSLAM_PROFILE label "sp_gpu_infer" (src/SuperPoint.cc:639: enqueue + scores D2H + sync of the mono
+// infer_device path).  Here the network, the selection and the gather are one asynchronous sequence, so the label receives
+// the DEVICE time of the library's sp_gpu_infer:* stages (hipEvents inside the library, sship_get_stage_timings) - what the
+// reference's wall-clock bracket measured minus its host waits.  Emitted for extract() (the path the reference labels) and
+// for extract_stereo() (one batch-2 pass; n = 1 per call) so a SUPERSLAM_PROFILE=1 run keeps every label it had.
+inline void profile_begin() {
+  if (superslam::Profiler::enabled()) sship_set_profiling(1);
+}
+inline void profile_emit_gpu_infer() {
+  if (!superslam::Profiler::enabled()) return;
+  const char* labels[32];
+  float ms[32];
+  const int n = sship_get_stage_timings(labels, ms, 32);
+  double gpu = 0.0;
+  for (int i = 0; i < n; ++i)
+    if (std::string(labels[i]).compare(0, 13, "sp_gpu_infer:") == 0) gpu += ms[i];
+  if (n > 0) superslam::Profiler::instance().add("sp_gpu_infer", gpu);
+}
 inline superslam::Features to_ref(superslam_hip::Features&& f) {
   superslam::Features o;
   to_cv(f.keypoints, o.keypoints);
@@ -62,12 +80,17 @@ public:
   }
   superslam::Features extract(const cv::Mat& image) override {
     cv::Mat keep;
-    return superslam_hip_adapter::to_ref(impl_.extract(superslam_hip_adapter::as_image(image, keep)));
+    superslam_hip_adapter::profile_begin();
+    auto f = impl_.extract(superslam_hip_adapter::as_image(image, keep));
+    superslam_hip_adapter::profile_emit_gpu_infer();  // src/SuperPoint.cc:639
+    return superslam_hip_adapter::to_ref(std::move(f));
   }
   std::pair<superslam::Features, superslam::Features> extract_stereo(const cv::Mat& left, const cv::Mat& right) override {
     SUPERSLAM_PROFILE_SCOPE("sp_extract_stereo");
     cv::Mat kl, kr;
+    superslam_hip_adapter::profile_begin();
     auto lr = impl_.extract_stereo(superslam_hip_adapter::as_image(left, kl), superslam_hip_adapter::as_image(right, kr));
+    superslam_hip_adapter::profile_emit_gpu_infer();
     return {superslam_hip_adapter::to_ref(std::move(lr.first)), superslam_hip_adapter::to_ref(std::move(lr.second))};
   }
 

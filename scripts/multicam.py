@@ -31,17 +31,14 @@ def main():
     import torch.distributed as dist
 
     from superslam_amd import LightGlue, SuperPoint, _lib
-    from superslam_amd.shard import all_gather_features, pair_schedule, shard_block
+    from superslam_amd.shard import all_gather_features, dist_env, init_process_group, pair_schedule, shard_block
     from superslam_amd.synth import make_frame
     from superslam_amd.weights import make_lightglue_weights, make_superpoint_weights, save_safetensors
 
-    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local, world, use_dist, backend = dist_env()
     torch.cuda.set_device(local)
-    use_dist = "RANK" in os.environ
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        init_process_group(backend, local)
     _lib.init(local)
     wdir = tempfile.mkdtemp(prefix="sship_w")
     save_safetensors(make_superpoint_weights(0), os.path.join(wdir, "sp.safetensors"))

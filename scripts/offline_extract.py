@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--w", type=int, default=752)
     ap.add_argument("--max-kp", type=int, default=600)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered (desc, kp, n) to this .npz (the multi-rank rehearsal test "
+                                                  "compares it bit-for-bit with a single-process run)")
     args = ap.parse_args()
 
     import numpy as np
@@ -34,17 +36,14 @@ def main():
     import torch.distributed as dist
 
     from superslam_amd import SuperPoint, _lib
-    from superslam_amd.shard import HostDescriptorPool, all_gather_features, shard_block
+    from superslam_amd.shard import HostDescriptorPool, all_gather_features, dist_env, init_process_group, shard_block
     from superslam_amd.synth import make_frame
     from superslam_amd.weights import make_superpoint_weights, save_safetensors
 
-    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local, world, use_dist, backend = dist_env()
     torch.cuda.set_device(local)
-    use_dist = "RANK" in os.environ
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        init_process_group(backend, local)
     _lib.init(local)
     wdir = tempfile.mkdtemp(prefix="sship_w")
     save_safetensors(make_superpoint_weights(0), os.path.join(wdir, "sp.safetensors"))
@@ -74,7 +73,7 @@ def main():
     if use_dist:
         dist.barrier()
     t_ext = time.perf_counter() - t0
-    out = {"frames": args.frames, "ranks": world, "frames_per_s": round(args.frames / t_ext, 1)}
+    out = {"frames": args.frames, "ranks": world, "frames_per_s": round(args.frames / t_ext, 1), "backend": backend if use_dist else None}
     if use_dist:
         t0 = time.perf_counter()
         gd, gk, gn = all_gather_features(desc, kp, n, args.frames)
@@ -87,6 +86,8 @@ def main():
         pool = HostDescriptorPool(gd, gk, gn)        # the shared host descriptor-pool image
         kp0, d0 = pool.features(0)
         out["frame0_keypoints"] = int(kp0.shape[0]); out["pool_bytes"] = int(pool.desc.numel() * 2)
+        if args.dump:
+            np.savez(args.dump, desc=pool.desc.numpy(), kp=pool.kp.numpy(), n=pool.n.numpy())
         print(json.dumps(out), flush=True)
     sp.close()
     if use_dist:

@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_t -o t_$c -- python $R/bench.py --headline-only --steps 2 --warmup 1 --chunks 2 --pairs $P > /tmp/pmc_t/run_$c.log 2>&1
 done
 python - "$R" "$P" "$OUT" <<'PY'
-import json, sqlite3, sys
+import hashlib, json, sqlite3, sys, time
 root, pairs, outp = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -37,6 +37,9 @@ for name, d in per.items():
     kernels[short] = {"launches": max(len(f), len(w)), "FETCH_SIZE_KB_mean": fm, "WRITE_SIZE_KB_mean": wm,
                       "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0}
 out = {"pairs_per_call": pairs, "images_per_launch": 2 * pairs, "headline_launches_only": True,
+       # provenance (bench.py prints it next to roofline.traffic: the value is read from this file, not measured in the bench run)
+       "collected_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+       "conv_pp_sha16": hashlib.sha256(open(f"{root}/superslam_amd/csrc/conv_pp.hip", "rb").read()).hexdigest()[:16],
        "command": f"bench.py --headline-only --steps 2 --warmup 1 --chunks 2 --pairs {pairs}",
        "note": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (mean over the launches of the trace, all of them headline "
                "launches); separate --pmc passes", "kernels": kernels}

@@ -22,7 +22,7 @@ namespace sship {
 
 static thread_local std::string g_err;
 static void (*g_log_cb)(int, const char*) = nullptr;
-static bool g_profiling = false;
+static int g_profiling = 0;  // 0 off, 1 stage marks, 2 stage marks + one mark per SuperPoint layer launch (sship_set_profiling)
 
 void set_error(const std::string& msg) {
   g_err = msg;
@@ -335,16 +335,23 @@ static int require_device() {
 struct StageTimer {
   std::vector<std::pair<const char*, hipEvent_t>> marks;
   std::vector<std::pair<std::string, float>> last;
-  ~StageTimer() { clear(); }
+  // No destructor work: a thread_local's destructor can run after the HIP runtime has been torn down (process exit,
+  // or a thread that outlives hipDeviceReset) and hipEventDestroy there is undefined; at most 64 events leak per thread.
   void begin(hipStream_t s) { if (!g_profiling) return; clear(); mark("start", s); }
   // a matcher entered on its own (no extractor call in front of it on this thread) opens its own sequence
   void begin_if_idle(hipStream_t s) { if (g_profiling && marks.empty()) mark("start", s); }
   void mark(const char* label, hipStream_t s) {
     if (!g_profiling) return;
-    if (marks.size() >= 64) clear();  // nobody collected: do not accumulate events without bound
+    if (marks.size() >= 64) {  // nobody collected: do not accumulate events without bound; re-arm so the next interval
+      clear();                 // is measured from here, not from an arbitrary earlier stage
+      hipEvent_t e0;
+      if (hipEventCreate(&e0) == hipSuccess) { (void)hipEventRecord(e0, s); marks.push_back({"start", e0}); }
+    }
     hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s); marks.push_back({label, e});
   }
+  // per-layer marks (level 2 only)
+  void mark_fine(const char* label, hipStream_t s) { if (g_profiling >= 2) mark(label, s); }
   void clear() { for (auto& m : marks) (void)hipEventDestroy(m.second); marks.clear(); }
   void collect() {
     if (marks.size() < 2) return;
@@ -369,7 +376,7 @@ using namespace sship;
 extern "C" int sship_version(void) { return SSHIP_VERSION; }
 extern "C" const char* sship_last_error(void) { return g_err.c_str(); }
 extern "C" void sship_set_log_callback(void (*cb)(int, const char*)) { g_log_cb = cb; }
-extern "C" void sship_set_profiling(int on) { g_profiling = on != 0; }
+extern "C" void sship_set_profiling(int level) { g_profiling = level < 0 ? 0 : level > 2 ? 2 : level; }
 extern "C" int sship_get_stage_timings(const char** labels, float* ms, int max_stages) {
   bind_thread();
   g_timer.collect();
@@ -572,6 +579,7 @@ struct sship_sp {
   PinBuf h_kp, h_n, h_img;
   int cap = 0;
   float thr_f = 0.f;
+  bool img_valid = false;  // sp->img holds the pixels of the last call (host-image paths always; batch path under profiling)
   // decode-ahead upload ring (sship_sp_ring_*): `depth` stereo frames in pinned host memory + their device copies
   struct Ring {
     int depth = 0, h = 0, w = 0, ch = 0;
@@ -658,21 +666,30 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
   // conv1a is evaluated inside conv1b's tile staging (conv_pp.hip): the 64-channel full-resolution activation
   // never exists in HBM.
+  // level-2 profiling: one mark per launch ("sp_gpu_infer:encoder/<layer>"); the LAST launch of a group carries the group's
+  // level-1 label, so summing a scope's stages gives the same figure at either level
   SSHIP_HIP_CHECK(conv1ab(sp, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
+  g_timer.mark_fine("sp_gpu_infer:encoder/conv1a+conv1b+pool", s);
   SSHIP_HIP_CHECK(conv3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));
+  g_timer.mark_fine("sp_gpu_infer:encoder/conv2a", s);
   SSHIP_HIP_CHECK(conv3(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, s));
+  g_timer.mark_fine("sp_gpu_infer:encoder/conv2b+pool", s);
   SSHIP_HIP_CHECK(conv3(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, s));
+  g_timer.mark_fine("sp_gpu_infer:encoder/conv3a", s);
   SSHIP_HIP_CHECK(conv3(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, s));
+  g_timer.mark_fine("sp_gpu_infer:encoder/conv3b+pool", s);
   SSHIP_HIP_CHECK(conv3(sp->c4a, sp->a3b.as<_Float16>(), sp->a4a.as<_Float16>(), B, Hc, Wc, false, s));
+  g_timer.mark_fine("sp_gpu_infer:encoder/conv4a", s);
   SSHIP_HIP_CHECK(conv3(sp->c4b, sp->a4a.as<_Float16>(), sp->a4b.as<_Float16>(), B, Hc, Wc, false, s));
-  g_timer.mark("sp_gpu_infer:encoder", s);
+  g_timer.mark(g_profiling >= 2 ? "sp_gpu_infer:encoder/conv4b" : "sp_gpu_infer:encoder", s);
   SSHIP_HIP_CHECK(conv3(sp->cPa, sp->a4b.as<_Float16>(), sp->aPa.as<_Float16>(), B, Hc, Wc, false, s));
+  g_timer.mark_fine("sp_gpu_infer:heads/convPa", s);
   SSHIP_HIP_CHECK(sp_conv1x1_f32(sp->cPb, sp->aPa.as<_Float16>(), sp->logits.as<float>(), kLogitStride, B, Hc, Wc, s));
   // the dense descriptor branch (convDa, convDb) is only materialised for the dense API; extraction evaluates both
   // layers at the selected keypoints (k_desc_head_sparse).  SUPERSLAM_HIP_DESC=dense: dense convDa + gather (A/B runs).
   if (dense_desc || desc_dense_mode()) SSHIP_HIP_CHECK(conv3(sp->cDa, sp->a4b.as<_Float16>(), sp->aDa.as<_Float16>(), B, Hc, Wc, false, s));
   if (dense_desc) SSHIP_HIP_CHECK(sp_conv1x1_f16(sp->cDb, sp->aDa.as<_Float16>(), sp->draw.as<_Float16>(), B, Hc, Wc, s));
-  g_timer.mark("sp_gpu_infer:heads", s);
+  g_timer.mark(g_profiling >= 2 ? "sp_gpu_infer:heads/convPb" : "sp_gpu_infer:heads", s);
   return SSHIP_OK;
 }
 
@@ -687,6 +704,7 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
   a.cand = sp->cand.as<unsigned long long>(); a.cand_count = sp->cand_count.as<int>(); a.cap = sp->cap;
   a.scores_out = scores_out;
   launch_nms_tile(0, a, s);
+  g_timer.mark_fine("sp_extract_stereo:select/nms_tile", s);
   TopkArgs t{};
   t.cand = a.cand; t.cand_count = a.cand_count; t.cap = sp->cap; t.max_kp = sp->cfg.max_keypoints;
   t.score_w = Wc * 8;
@@ -696,7 +714,7 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
   t.n_out = n_out; t.n_cand_out = nullptr;
   launch_topk(t, B, s);
   SSHIP_HIP_CHECK(hipGetLastError());
-  g_timer.mark("sp_extract_stereo:select", s);
+  g_timer.mark(g_profiling >= 2 ? "sp_extract_stereo:select/topk" : "sp_extract_stereo:select", s);
   return SSHIP_OK;
 }
 
@@ -816,6 +834,12 @@ extern "C" int sship_sp_extract_batch_device(sship_sp* sp, const uint8_t* imgs, 
   // to each handle's private stream, which are ordered with the NULL stream but not with one another.)
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = sp_ensure(sp, batch, h, w)) return rc;
+  // a profiled call keeps a copy of its input in the handle: sship_sp_bench_layer re-launches layers on the buffers this
+  // call leaves behind, and a conv1a+conv1b launch on an all-zero image clocks ~7 % higher than on real pixels (the chip
+  // runs at its power limit; low-toggle operands draw less) - the figure would flatter the kernel
+  if (g_profiling && imgs != sp->img.as<uint8_t>())
+    SSHIP_HIP_CHECK(hipMemcpyAsync(sp->img.p, imgs, (size_t)batch * h * w, hipMemcpyDeviceToDevice, s));
+  sp->img_valid = g_profiling != 0 || imgs == sp->img.as<uint8_t>();
   g_timer.begin(s);
   if (int rc = sp_network(sp, imgs, batch, h, w, s, false)) return rc;
   if (int rc = sp_select(sp, batch, h, w, nullptr, kp_out, n_out, s)) return rc;
@@ -861,6 +885,9 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
   bind_thread();
   if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 14) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");
   if (batch > sp->wsB || h != sp->wsH || w != sp->wsW) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: run the network at this shape first");
+  if (layer <= 1 && !sp->img_valid)
+    return fail(SSHIP_ERR_INVALID, "sp_bench_layer: the handle holds no copy of the last input - make one call with sship_set_profiling(1) first "
+                                   "(a launch on stale / zero pixels runs at a higher clock than the real one)");
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
   hipStream_t s = sp->stream;
@@ -951,6 +978,7 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
     SSHIP_HIP_CHECK(hipMemcpyAsync(sp->gray_in.p, hp, img_bytes * B, hipMemcpyHostToDevice, s));
     launch_bgr2gray(sp->gray_in.as<uint8_t>(), B * h * w, sp->img.as<uint8_t>(), s);
   }
+  sp->img_valid = true;
   return sp_extract_device(sp, sp->img.as<uint8_t>(), B, h, w, outs);
 }
 // `gray`: B u8 images [h][w] resident on the device, ordered with sp->stream
@@ -1456,22 +1484,35 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   else if ((size_t)2 * (pairs / 2) * lg->NP / 64 >= (size_t)2 * cu_count()) parts = 2;
   if (parts > 1) {
     SSHIP_HIP_CHECK(hipEventRecord(lg->ev_fork, s));
+    // Once an auxiliary stream has been forked, every exit - including an error part-way - joins it back into `s` first:
+    // work already queued on the (non-blocking) auxiliary streams would otherwise be unordered with the caller's stream and
+    // the next call's k_lg_prep could overwrite x / rope / lens_c while an auxiliary stream still reads them.
+    int forked = 0, rc = SSHIP_OK;
+    hipError_t he = hipSuccess;
     int p0 = pairs / parts;  // part 0 (on s) is launched last: the auxiliary streams are already busy by then
-    for (int i = 1; i < parts; ++i) {
+    for (int i = 1; i < parts && rc == SSHIP_OK && he == hipSuccess; ++i) {
       const int np = i + 1 < parts ? pairs / parts : pairs - p0;
-      SSHIP_HIP_CHECK(hipStreamWaitEvent(lg->aux[i - 1], lg->ev_fork, 0));
-      if (int rc = layers(p0, np, lg->aux[i - 1], true)) return rc;
-      SSHIP_HIP_CHECK(hipEventRecord(lg->ev_join[i - 1], lg->aux[i - 1]));
+      if ((he = hipStreamWaitEvent(lg->aux[i - 1], lg->ev_fork, 0)) != hipSuccess) break;
+      forked = i;
+      rc = layers(p0, np, lg->aux[i - 1], true);
       p0 += np;
     }
-    if (int rc = layers(0, pairs / parts, s, true)) return rc;
-    for (int i = 1; i < parts; ++i) SSHIP_HIP_CHECK(hipStreamWaitEvent(s, lg->ev_join[i - 1], 0));
+    if (rc == SSHIP_OK && he == hipSuccess) rc = layers(0, pairs / parts, s, true);
+    for (int i = 1; i <= forked; ++i) {  // join (also on the error path; best effort there)
+      hipError_t e1 = hipEventRecord(lg->ev_join[i - 1], lg->aux[i - 1]);
+      if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, lg->ev_join[i - 1], 0);
+      if (e1 != hipSuccess) { (void)hipStreamSynchronize(lg->aux[i - 1]); if (he == hipSuccess) he = e1; }
+    }
+    if (rc != SSHIP_OK) return rc;
+    SSHIP_HIP_CHECK(he);
   } else {
     if (int rc = layers(0, pairs, s, false)) return rc;
   }
   SSHIP_HIP_CHECK(hipGetLastError());
   g_timer.mark("fe_lg_stereo_match:layers_x9", s);
   if (n_layers < kLgLayers) {  // truncated debug run: x after layer n_layers is the product; no assignment
+    lg->debug_layers = kLgLayers;  // one-shot: a caller that forgets to reset it must not keep a matcher that matches nothing
+    log_msg(3, "sship: LightGlue ran truncated to %d layer(s) (sship_lg_debug_set_layers, test-only); matches0 = -1", n_layers);
     SSHIP_HIP_CHECK(hipMemsetAsync(m0, 0xff, (size_t)pairs * lg->max_kp * 4, s));
     SSHIP_HIP_CHECK(hipMemsetAsync(ms0, 0, (size_t)pairs * lg->max_kp * 4, s));
     return SSHIP_OK;

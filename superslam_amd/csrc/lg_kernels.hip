@@ -1270,6 +1270,9 @@ static hipError_t launch_ffn4(int tokens, hipStream_t s, A... args) {
 // the 8-wave kernel everywhere (A/B runs)
 static bool use_ffn4(int tokens) {
   static const int env = getenv("SUPERSLAM_HIP_FFN") ? atoi(getenv("SUPERSLAM_HIP_FFN")) : 0;
+  // k_lg_ffn4 addresses x / q / k / v^T through buffer resources with 32-bit byte offsets (token * 512 B): beyond ~2 GiB of
+  // token stream its out-of-range stores would be dropped silently - such launches use the 8-wave kernel (64-bit addresses)
+  if ((size_t)tokens * 512 >= 0x7f000000ull) return false;
   if (env == 8) return false;
   if (env == 4) return tokens % 64 == 0;
   return tokens % 64 == 0 && tokens / 64 >= 2 * cu_count();

@@ -34,6 +34,45 @@ def pair_schedule(n_cameras: int, world: int) -> List[List[Tuple[int, int]]]:
     return out
 
 
+def dist_env():
+    """(rank, device index, world size, under a launcher?, backend) of this process.
+
+    One process per GPU: the device is LOCAL_RANK unless SUPERSLAM_HIP_DEVICE pins it (the single-GPU multi-rank rehearsal runs
+    every rank on device 0).  The backend is RCCL ("nccl") unless SUPERSLAM_DIST_BACKEND says otherwise - RCCL refuses two ranks
+    on one device, so that rehearsal falls back to "gloo" (collectives staged through the host) and still executes the same
+    sharding / gather / timing code the 8-GPU run does."""
+    import os
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = int(os.environ.get("SUPERSLAM_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    return rank, dev, world, "RANK" in os.environ, os.environ.get("SUPERSLAM_DIST_BACKEND", "nccl")
+
+
+def init_process_group(backend: str, device_index: int):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+    else:
+        dist.init_process_group(backend)
+
+
+def all_reduce_max_seconds(dt: float) -> float:
+    """max over ranks of a wall-clock interval (the slowest rank defines the step time)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def all_gather_features(desc, kp, n, total_units: int, group=None):
     """Gather per-rank padded results into global tensors ordered by unit id (block sharding).
 
@@ -47,7 +86,11 @@ def all_gather_features(desc, kp, n, total_units: int, group=None):
     world = dist.get_world_size(group)
     per = (total_units + world - 1) // world
     outs = []
+    via_host = dist.get_backend(group) != "nccl" and desc.is_cuda   # gloo: device tensors are staged through the host
+    home = desc.device
     for t in (desc, kp, n):
+        if via_host:
+            t = t.cpu()
         pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
         full = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -61,7 +104,7 @@ def all_gather_features(desc, kp, n, total_units: int, group=None):
         for r in range(world):
             a, b = shard_block(total_units, r, world)
             keep.append(full[r * per: r * per + (b - a)])
-        outs.append(torch.cat(keep, 0))
+        outs.append(torch.cat(keep, 0).to(home) if via_host else torch.cat(keep, 0))
     return tuple(outs)
 
 

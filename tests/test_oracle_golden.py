@@ -189,3 +189,30 @@ def test_lightglue_tiny_assignment_by_hand():
     assert m0[0].tolist() == [0, 1, -1]          # row 2's best column (1) prefers row 1 -> not mutual
     assert ms0[0, 2].item() == 0.0
     assert ms0[0, 0].item() > 0.99
+
+
+# ------------------------------------------------------------------------------------------------------
+# pin-when-possible (VERDICT r02 "do this" 5): scripts/pin_oracles.py turns the two unpinned oracles green on a machine that
+# has the third-party packages.  Here (no `lightglue`, no torchvision / hub model) it must import, skip cleanly (exit status 3),
+# leave the fixtures untouched, and the stamp it would write must be absent - "parity unpinned" stays the honest label.
+# ------------------------------------------------------------------------------------------------------
+def test_pin_script_imports_and_skips_cleanly_without_the_packages(golden_dir):
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pin_oracles", os.path.join(root, "scripts", "pin_oracles.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    before = open(os.path.join(golden_dir, "meta.json")).read()
+    if mod.lightglue_available():
+        pytest.skip("the lightglue package IS importable here: run `python scripts/pin_oracles.py --write` and commit the stamp")
+    assert mod.main(["--lightglue"]) == 3
+    assert mod.main(["--lightglue", "--write"]) == 3
+    assert open(os.path.join(golden_dir, "meta.json")).read() == before
+    meta = json.loads(before)
+    assert "lightglue_pinned" not in meta, "a pin stamp is committed: drop the 'parity unpinned' labels in DESIGN.md / oracle/lightglue_ref.py"
+    # the fixtures the script compares are the committed ones
+    g = np.load(os.path.join(golden_dir, "lightglue_selfcheck.npz"))
+    for tag in mod.CASES:
+        assert tag + "_matches0" in g.files and tag + "_mscores0" in g.files

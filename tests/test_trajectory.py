@@ -103,3 +103,19 @@ def test_kitti_segment_errors_on_known_drift():
     assert abs(k["r_rel_deg_per_m"] - 0.01) < 5e-4 and k["t_rel_percent"] > 0.5
     short = _drive(50)                                 # shorter than the smallest segment
     assert np.isnan(T.kitti_segments(short, short)["t_rel_percent"])
+
+
+def test_kitti00_gate_recipe_is_well_formed():
+    """scripts/run_kitti00_gate.sh (BASELINE configs[3]) cannot run here - no dataset, GTSAM, OpenCV or real weights - but it must
+    parse, refuse to start without its three paths, and use this package's ATE with the reference's published figure."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sh = os.path.join(root, "scripts", "run_kitti00_gate.sh")
+    assert subprocess.run(["bash", "-n", sh]).returncode == 0
+    env = {k: v for k, v in os.environ.items() if k not in ("SUPERSLAM", "KITTI", "WEIGHTS")}
+    r = subprocess.run(["bash", sh], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "SUPERSLAM" in r.stderr
+    text = open(sh).read()
+    assert "1.582" in text and "superslam_amd.trajectory" in text and "--no-viewer" in text
