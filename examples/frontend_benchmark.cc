@@ -20,7 +20,11 @@
 // build:  g++ -std=c++17 -O2 -Iinclude examples/frontend_benchmark.cc -o frontend_benchmark
 //             -Lsuperslam_amd/lib -lsuperslam_hip -Wl,-rpath,$PWD/superslam_amd/lib -Wl,-rpath,/opt/rocm/lib -lpthread -lz
 // run:    ./frontend_benchmark --sp sp.safetensors --lg lg.safetensors (--sequence DIR | --synthetic 200) [--keyframe-match]
-//                              [--max-kp 600] [--threshold 0.005] [--border 4] [--no-ring]
+//                              [--max-kp 600] [--threshold 0.005] [--border 4] [--no-ring] [--no-pipeline]
+//
+// Cross-frame pipelining (default with the ring; --no-pipeline turns it off): as soon as frame t's extraction has returned, frame
+// t+1's extraction is ENQUEUED on the extractor's stream (sship_sp_ring_submit) - before frame t's LightGlue match - so the next
+// frame's SuperPoint kernels share the GPU with this frame's matcher, whose launches cover a fraction of the CUs at one pair.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -82,7 +86,17 @@ struct Source {
   bool load(int ni, int rows, int cols, uint8_t* left, uint8_t* right) const {
     if (synthetic > 0) {
       if (ni >= synthetic) return false;
-      synth_pair(ni, rows, cols, left, right);
+      // eight distinct pairs, generated once and cycled: "decoding" a synthetic frame then costs a memcpy, like reading an
+      // already-decoded image - the procedural generator itself (several ms per pair) would be the slowest stage of the run
+      static std::vector<std::vector<uint8_t>> cache;
+      static int crows = 0, ccols = 0;
+      if (cache.empty() || crows != rows || ccols != cols) {
+        cache.assign(16, std::vector<uint8_t>((size_t)rows * cols));
+        for (int k = 0; k < 8; ++k) synth_pair(k, rows, cols, cache[2 * k].data(), cache[2 * k + 1].data());
+        crows = rows; ccols = cols;
+      }
+      std::memcpy(left, cache[2 * (ni % 8)].data(), (size_t)rows * cols);
+      std::memcpy(right, cache[2 * (ni % 8) + 1].data(), (size_t)rows * cols);
       return true;
     }
     if (count && (size_t)ni >= count) return false;
@@ -102,7 +116,7 @@ int main(int argc, char** argv) {
   Source src;
   int max_kp = 600, border = 4;
   double thr = 0.005;
-  bool keyframe = false, use_ring = true;
+  bool keyframe = false, use_ring = true, pipeline = true;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -115,11 +129,12 @@ int main(int argc, char** argv) {
     else if (a == "--border") border = std::atoi(next());
     else if (a == "--keyframe-match") keyframe = true;
     else if (a == "--no-ring") use_ring = false;
+    else if (a == "--no-pipeline") pipeline = false;
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
   if (sp_path.empty() || lg_path.empty() || (src.sequence.empty() && src.synthetic <= 0)) {
     std::fprintf(stderr, "usage: %s --sp W.safetensors --lg W.safetensors (--sequence DIR | --synthetic N) [--keyframe-match] "
-                         "[--max-kp 600] [--threshold 0.005] [--border 4] [--no-ring]\n", argv[0]);
+                         "[--max-kp 600] [--threshold 0.005] [--border 4] [--no-ring] [--no-pipeline]\n", argv[0]);
     return 2;
   }
 
@@ -177,7 +192,7 @@ int main(int argc, char** argv) {
   });
 
   std::vector<float> ms;
-  long stereo_points = 0, stereo_matches = 0, track_matches = 0;
+  long stereo_points = 0, stereo_matches = 0, track_matches = 0, submitted_ahead = 0;
   sh::Features prev_left;
   const auto wall0 = std::chrono::steady_clock::now();
   for (int ni = 0;; ++ni) {
@@ -189,8 +204,14 @@ int main(int argc, char** argv) {
     const int slot = ni % kDepth;
     const auto t1 = std::chrono::steady_clock::now();
     std::pair<sh::Features, sh::Features> feats;
-    if (use_ring) feats = extractor.extract_stereo_ring(slot);
-    else feats = extractor.extract_stereo(sh::Image{plain[2 * slot].data(), rows, cols, 1, 0}, sh::Image{plain[2 * slot + 1].data(), rows, cols, 1, 0});
+    if (use_ring) {
+      feats = extractor.extract_stereo_ring(slot);   // a submitted slot: waits for its completion event only
+      if (pipeline) {  // frame ni + 1 already decoded and uploading?  enqueue its extraction now, ahead of this frame's match
+        bool have_next;
+        { std::lock_guard<std::mutex> lk(mu); have_next = produced > ni + 1; }
+        if (have_next && extractor.ring_submit((ni + 1) % kDepth)) ++submitted_ahead;
+      }
+    } else feats = extractor.extract_stereo(sh::Image{plain[2 * slot].data(), rows, cols, 1, 0}, sh::Image{plain[2 * slot + 1].data(), rows, cols, 1, 0});
     sh::MatchResult lr = matcher.match(feats.first.keypoints, feats.first.descriptors, feats.second.keypoints, feats.second.descriptors);
     for (const sh::DMatch& m : lr.matches) {  // StereoFrontEnd's gate
       const sh::KeyPoint &kl = feats.first.keypoints[m.queryIdx], &kr = feats.second.keypoints[m.trainIdx];
@@ -217,6 +238,7 @@ int main(int argc, char** argv) {
   std::printf("source           : %s, %dx%d, %s%s\n", src.synthetic > 0 ? "synthetic" : (src.ext == "png" ? "PNG sequence" : "PGM sequence"), cols, rows,
               use_ring ? "pinned upload ring" : "copying host API", ts.empty() ? "" : ", times.txt");
   std::printf("frames           : %zu\n", ms.size());
+  if (use_ring) std::printf("pipelined        : %s (%ld of %zu extractions enqueued one frame ahead)\n", pipeline ? "yes" : "no", submitted_ahead, ms.size());
   std::printf("per-frame ms      mean=%.2f p50=%.2f p95=%.2f max=%.2f\n", mean, percentile(ms, 0.50), percentile(ms, 0.95), percentile(ms, 1.0));
   std::printf("throughput        : %.2f fps over %.1fs wall\n", wall > 0 ? ms.size() / wall : 0.0, wall);
   std::printf("real-time (>=10fps): %s\n", mean > 0 && (1000.0 / mean) >= 10.0 ? "YES" : "NO");

@@ -156,6 +156,15 @@ int sship_sp_ring_create(sship_sp* sp, int depth, int h, int w, int channels);
 uint8_t* sship_sp_ring_host(sship_sp* sp, int slot, int image /* 0 left, 1 right */);
 int sship_sp_ring_upload(sship_sp* sp, int slot);
 int sship_sp_extract_stereo_ring(sship_sp* sp, int slot, sship_features* out_left, sship_features* out_right);
+/* Cross-frame pipelining for the per-frame path (no reference counterpart: the reference runs extract -> match -> estimator
+ * strictly in sequence, src/StereoFrontEnd.cc:10-48).  sship_sp_ring_submit ENQUEUES the whole extraction of an uploaded slot
+ * (network, selection, descriptor head into two freshly acquired pool slots, D2H of keypoints / counts into the slot's own
+ * pinned buffers) on the extractor's stream and returns at once; the later sship_sp_extract_stereo_ring(slot) only waits for
+ * that work's completion event and hands the results out.  Called right after frame t's extraction has returned - before frame
+ * t's LightGlue match - it lets frame t+1's SuperPoint kernels share the GPU with frame t's matcher (the matcher's launches
+ * cover a fraction of the CUs at one pair).  Same thread as every other call on this handle; at most one submission per slot;
+ * other extractor calls in between are ordered by the handle's stream and do not disturb a pending submission. */
+int sship_sp_ring_submit(sship_sp* sp, int slot);
 /* SuperPoint::infer host path (src/SuperPoint.cc:322-348,427-528): keypoints + CV_32F [n,256] descriptors
  * on the host.  kp_xys [3*max_kp], desc_f32 [max_kp*256]. */
 int sship_sp_infer_host(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels,

@@ -223,6 +223,12 @@ public:
   }
   uint8_t* ring_host(int slot, int image) { return sp_ ? sship_sp_ring_host(sp_, slot, image) : nullptr; }
   bool ring_upload(int slot) { return sp_ && sship_sp_ring_upload(sp_, slot) == SSHIP_OK; }
+  // enqueue the extraction of an uploaded slot ahead of time (sship_sp_ring_submit): extract_stereo_ring(slot) then only waits
+  bool ring_submit(int slot) {
+    if (!sp_) return false;
+    if (sship_sp_ring_submit(sp_, slot) != SSHIP_OK) { last_error_ = sship_last_error(); return false; }
+    return true;
+  }
   std::pair<Features, Features> extract_stereo_ring(int slot) {
     Features l, r;
     if (!sp_) return {l, r};

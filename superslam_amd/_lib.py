@@ -62,6 +62,7 @@ _SIGS = {
     "sship_sp_ring_host": (vp, [vp, ip, ip]),
     "sship_sp_ring_upload": (ip, [vp, ip]),
     "sship_sp_extract_stereo_ring": (ip, [vp, ip, C.POINTER(Features), C.POINTER(Features)]),
+    "sship_sp_ring_submit": (ip, [vp, ip]),
     "sship_sp_extract_batch_device": (ip, [vp, vp, ip, ip, ip, vp, vp, vp, vp]),
     "sship_sp_dense": (ip, [vp, vp, ip, ip, ip, vp, vp, vp, vp]),
     "sship_lg_weights_load": (ip, [C.c_char_p, C.POINTER(vp)]),

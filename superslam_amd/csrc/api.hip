@@ -587,6 +587,9 @@ struct sship_sp {
     std::vector<void*> host, dev;     // [depth]: left image then right image, contiguous
     std::vector<hipEvent_t> uploaded;  // [depth]
     hipStream_t copy_stream = nullptr;
+    // sship_sp_ring_submit: an extraction enqueued ahead of the call that collects it
+    struct Pending { bool active = false; int slots[2] = {-1, -1}; int rc_pool = 0; hipEvent_t done = nullptr; void* h_kp = nullptr; void* h_n = nullptr; };
+    std::vector<Pending> pending;      // [depth]
   } ring;
 };
 
@@ -981,39 +984,45 @@ static int sp_extract_host(sship_sp* sp, const uint8_t* const* imgs, int B, int 
   sp->img_valid = true;
   return sp_extract_device(sp, sp->img.as<uint8_t>(), B, h, w, outs);
 }
-// `gray`: B u8 images [h][w] resident on the device, ordered with sp->stream
-static int sp_extract_device(sship_sp* sp, const uint8_t* gray, int B, int h, int w, sship_features* const* outs) {
+// `gray`: B u8 images [h][w] resident on the device, ordered with sp->stream.
+// Enqueue: network + selection + descriptor head into freshly acquired pool slots + D2H of keypoints / counts into the given
+// pinned buffers - everything asynchronous on sp->stream.  slots[b] = -1 where the pool was exhausted (*rc_pool set).
+static int sp_extract_enqueue(sship_sp* sp, const uint8_t* gray, int B, int h, int w, int* slots, int* rc_pool, float* h_kp, int* h_n) {
   hipStream_t s = sp->stream;
   g_timer.begin(s);
-  for (int b = 0; b < B; ++b) { outs[b]->n = 0; outs[b]->desc_dev = nullptr; outs[b]->slot = -1; }
+  *rc_pool = SSHIP_OK;
+  for (int b = 0; b < B; ++b) slots[b] = -1;
   if (int rc = sp_network(sp, gray, B, h, w, s, false)) return rc;
   if (int rc = sp_select(sp, B, h, w, nullptr, sp->kp.as<float>(), sp->n_dev.as<int>(), s)) return rc;
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(h, w, H2, W2, H4, W4, Hc, Wc);
   const int mk = sp->cfg.max_keypoints;
-  int rc_pool = SSHIP_OK;
   // a HIP failure after slots were acquired hands them back: the 8-slot pool must not shrink with every error
   auto give_back = [&](hipError_t e, const char* what) {
     (void)hipStreamSynchronize(s);
     for (int b = 0; b < B; ++b)
-      if (outs[b]->slot >= 0) { sship_pool_release(sp->pool, outs[b]->slot); outs[b]->slot = -1; outs[b]->desc_dev = nullptr; outs[b]->n = 0; }
+      if (slots[b] >= 0) { sship_pool_release(sp->pool, slots[b]); slots[b] = -1; }
     return fail(SSHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
   };
   for (int b = 0; b < B; ++b) {
-    outs[b]->slot = sship_pool_acquire(sp->pool);  // pool_->make(n), SuperPoint.cc:721
-    if (outs[b]->slot < 0) { rc_pool = SSHIP_ERR_POOL_EXHAUSTED; continue; }
+    slots[b] = sship_pool_acquire(sp->pool);  // pool_->make(n), SuperPoint.cc:721
+    if (slots[b] < 0) { *rc_pool = SSHIP_ERR_POOL_EXHAUSTED; continue; }
     if (hipError_t e = desc_head(sp, b, Hc, Wc, sp->cell_h.as<int>() + (size_t)b * mk, sp->cell_w.as<int>() + (size_t)b * mk,
-                                 sp->n_dev.as<int>() + b, 1, static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, outs[b]->slot)), 0, s))
+                                 sp->n_dev.as<int>() + b, 1, static_cast<_Float16*>(sship_pool_slot_ptr(sp->pool, slots[b])), 0, s))
       return give_back(e, "sp_extract: descriptor head");
   }
   g_timer.mark("sp_extract_stereo:gather", s);
-  if (hipError_t e = hipMemcpyAsync(sp->h_kp.p, sp->kp.p, (size_t)B * mk * 12, hipMemcpyDeviceToHost, s)) return give_back(e, "sp_extract: D2H keypoints");
-  if (hipError_t e = hipMemcpyAsync(sp->h_n.p, sp->n_dev.p, (size_t)B * 4, hipMemcpyDeviceToHost, s)) return give_back(e, "sp_extract: D2H counts");
-  if (hipError_t e = hipStreamSynchronize(s)) return give_back(e, "sp_extract: stream synchronize");
+  if (hipError_t e = hipMemcpyAsync(h_kp, sp->kp.p, (size_t)B * mk * 12, hipMemcpyDeviceToHost, s)) return give_back(e, "sp_extract: D2H keypoints");
+  if (hipError_t e = hipMemcpyAsync(h_n, sp->n_dev.p, (size_t)B * 4, hipMemcpyDeviceToHost, s)) return give_back(e, "sp_extract: D2H counts");
+  return SSHIP_OK;
+}
+// Finish (after the stream / the completion event has been waited for): host copies into the caller's features.
+static int sp_extract_finish(sship_sp* sp, int B, const int* slots, int rc_pool, const float* h_kp, const int* h_n, sship_features* const* outs) {
+  const int mk = sp->cfg.max_keypoints;
   for (int b = 0; b < B; ++b) {
-    const int n = sp->h_n.as<int>()[b];
-    outs[b]->n = n;
-    if (outs[b]->kp_xys) memcpy(outs[b]->kp_xys, sp->h_kp.as<float>() + (size_t)b * mk * 3, (size_t)n * 12);
+    const int n = h_n[b];
+    outs[b]->n = n; outs[b]->slot = slots[b]; outs[b]->desc_dev = nullptr;
+    if (outs[b]->kp_xys) memcpy(outs[b]->kp_xys, h_kp + (size_t)b * mk * 3, (size_t)n * 12);
     if (outs[b]->slot >= 0) {
       if (n == 0) { sship_pool_release(sp->pool, outs[b]->slot); outs[b]->slot = -1; }  // empty handle, SuperPoint.cc:722-723
       else outs[b]->desc_dev = sship_pool_slot_ptr(sp->pool, outs[b]->slot);
@@ -1021,6 +1030,17 @@ static int sp_extract_device(sship_sp* sp, const uint8_t* gray, int B, int h, in
   }
   if (rc_pool) return fail(rc_pool, "SuperPoint: descriptor pool exhausted (no free slot)");
   return SSHIP_OK;
+}
+static int sp_extract_device(sship_sp* sp, const uint8_t* gray, int B, int h, int w, sship_features* const* outs) {
+  for (int b = 0; b < B; ++b) { outs[b]->n = 0; outs[b]->desc_dev = nullptr; outs[b]->slot = -1; }
+  int slots[2] = {-1, -1}, rc_pool = 0;
+  if (B > 2) return fail(SSHIP_ERR_INVALID, "sp_extract: at most two images per host call");
+  if (int rc = sp_extract_enqueue(sp, gray, B, h, w, slots, &rc_pool, sp->h_kp.as<float>(), sp->h_n.as<int>())) return rc;
+  if (hipError_t e = hipStreamSynchronize(sp->stream)) {
+    for (int b = 0; b < B; ++b) if (slots[b] >= 0) sship_pool_release(sp->pool, slots[b]);
+    return fail(SSHIP_ERR_HIP, std::string("sp_extract: stream synchronize: ") + hipGetErrorString(e));
+  }
+  return sp_extract_finish(sp, B, slots, rc_pool, sp->h_kp.as<float>(), sp->h_n.as<int>(), outs);
 }
 
 extern "C" int sship_sp_extract(sship_sp* sp, const uint8_t* img, int h, int w, int stride, int channels,
@@ -1045,6 +1065,15 @@ static void ring_free(sship_sp* sp) {
   for (void* p : r.host) if (p) (void)hipHostFree(p);
   for (void* p : r.dev) if (p) (void)hipFree(p);
   for (hipEvent_t e : r.uploaded) if (e) (void)hipEventDestroy(e);
+  for (auto& pd : r.pending) {
+    if (pd.active) {  // submitted, never collected: hand the pool slots back
+      if (pd.done) (void)hipEventSynchronize(pd.done);
+      for (int b = 0; b < 2; ++b) if (pd.slots[b] >= 0 && sp->pool) sship_pool_release(sp->pool, pd.slots[b]);
+    }
+    if (pd.done) (void)hipEventDestroy(pd.done);
+    if (pd.h_kp) (void)hipHostFree(pd.h_kp);
+    if (pd.h_n) (void)hipHostFree(pd.h_n);
+  }
   if (r.copy_stream) (void)hipStreamDestroy(r.copy_stream);
   r = sship_sp::Ring();
 }
@@ -1056,12 +1085,16 @@ extern "C" int sship_sp_ring_create(sship_sp* sp, int depth, int h, int w, int c
   auto& r = sp->ring;
   r.depth = depth; r.h = h; r.w = w; r.ch = channels; r.img_bytes = (size_t)h * w * channels;
   r.host.assign(depth, nullptr); r.dev.assign(depth, nullptr); r.uploaded.assign(depth, nullptr);
+  r.pending.assign(depth, sship_sp::Ring::Pending());
   auto bail = [&](const char* what, hipError_t e) { ring_free(sp); return fail(SSHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
   if (hipError_t e = hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking)) return bail("sp_ring_create: stream", e);
   for (int i = 0; i < depth; ++i) {
     if (hipError_t e = hipHostMalloc(&r.host[i], 2 * r.img_bytes, hipHostMallocDefault)) return bail("sp_ring_create: pinned host frame", e);
     if (hipError_t e = hipMalloc(&r.dev[i], 2 * r.img_bytes)) return bail("sp_ring_create: device frame", e);
     if (hipError_t e = hipEventCreateWithFlags(&r.uploaded[i], hipEventDisableTiming)) return bail("sp_ring_create: event", e);
+    if (hipError_t e = hipEventCreateWithFlags(&r.pending[i].done, hipEventDisableTiming)) return bail("sp_ring_create: event", e);
+    if (hipError_t e = hipHostMalloc(&r.pending[i].h_kp, (size_t)2 * sp->cfg.max_keypoints * 12, hipHostMallocDefault)) return bail("sp_ring_create: pinned keypoints", e);
+    if (hipError_t e = hipHostMalloc(&r.pending[i].h_n, 8, hipHostMallocDefault)) return bail("sp_ring_create: pinned counts", e);
   }
   return SSHIP_OK;
 }
@@ -1077,19 +1110,45 @@ extern "C" int sship_sp_ring_upload(sship_sp* sp, int slot) {
   SSHIP_HIP_CHECK(hipEventRecord(r.uploaded[slot], r.copy_stream));
   return SSHIP_OK;
 }
+static const uint8_t* ring_gray(sship_sp* sp, int slot) {  // the slot's pair as grayscale on the device, ordered with sp->stream
+  auto& r = sp->ring;
+  (void)hipStreamWaitEvent(sp->stream, r.uploaded[slot], 0);
+  if (r.ch == 3) {
+    launch_bgr2gray(static_cast<const uint8_t*>(r.dev[slot]), 2 * r.h * r.w, sp->img.as<uint8_t>(), sp->stream);
+    return sp->img.as<uint8_t>();
+  }
+  return static_cast<const uint8_t*>(r.dev[slot]);
+}
+extern "C" int sship_sp_ring_submit(sship_sp* sp, int slot) {
+  bind_thread();
+  if (!sp || slot < 0 || slot >= sp->ring.depth) return fail(SSHIP_ERR_INVALID, "sp_ring_submit: bad slot");
+  auto& r = sp->ring;
+  auto& pd = r.pending[slot];
+  if (pd.active) return fail(SSHIP_ERR_INVALID, "sp_ring_submit: this slot already has a submitted extraction (collect it with sship_sp_extract_stereo_ring)");
+  if (int rc = sp_ensure(sp, 2, r.h, r.w)) return rc;
+  const uint8_t* gray = ring_gray(sp, slot);
+  if (int rc = sp_extract_enqueue(sp, gray, 2, r.h, r.w, pd.slots, &pd.rc_pool, static_cast<float*>(pd.h_kp), static_cast<int*>(pd.h_n))) return rc;
+  SSHIP_HIP_CHECK(hipEventRecord(pd.done, sp->stream));
+  pd.active = true;
+  return SSHIP_OK;
+}
 extern "C" int sship_sp_extract_stereo_ring(sship_sp* sp, int slot, sship_features* out_left, sship_features* out_right) {
   bind_thread();
   if (!sp || !out_left || !out_right || slot < 0 || slot >= sp->ring.depth) return fail(SSHIP_ERR_INVALID, "sp_extract_stereo_ring: bad arguments");
   auto& r = sp->ring;
-  if (int rc = sp_ensure(sp, 2, r.h, r.w)) return rc;
-  SSHIP_HIP_CHECK(hipStreamWaitEvent(sp->stream, r.uploaded[slot], 0));
-  const uint8_t* gray = static_cast<const uint8_t*>(r.dev[slot]);
-  if (r.ch == 3) {
-    launch_bgr2gray(static_cast<const uint8_t*>(r.dev[slot]), 2 * r.h * r.w, sp->img.as<uint8_t>(), sp->stream);
-    gray = sp->img.as<uint8_t>();
-  }
   sship_features* outs[2] = {out_left, out_right};
-  return sp_extract_device(sp, gray, 2, r.h, r.w, outs);
+  auto& pd = r.pending[slot];
+  if (pd.active) {  // submitted ahead (sship_sp_ring_submit): wait for its completion event only
+    pd.active = false;
+    for (int b = 0; b < 2; ++b) { outs[b]->n = 0; outs[b]->desc_dev = nullptr; outs[b]->slot = -1; }
+    if (hipError_t e = hipEventSynchronize(pd.done)) {
+      for (int b = 0; b < 2; ++b) if (pd.slots[b] >= 0) sship_pool_release(sp->pool, pd.slots[b]);
+      return fail(SSHIP_ERR_HIP, std::string("sp_extract_stereo_ring: ") + hipGetErrorString(e));
+    }
+    return sp_extract_finish(sp, 2, pd.slots, pd.rc_pool, static_cast<const float*>(pd.h_kp), static_cast<const int*>(pd.h_n), outs);
+  }
+  if (int rc = sp_ensure(sp, 2, r.h, r.w)) return rc;
+  return sp_extract_device(sp, ring_gray(sp, slot), 2, r.h, r.w, outs);
 }
 extern "C" int sship_desc_to_host(const void* desc_dev, int count, int dim, float* out) {
   bind_thread();

@@ -160,25 +160,47 @@ __device__ __forceinline__ float max_xor32(float x) {
 #ifndef SSHIP_ATTN_TRACE_BUILD
 #define SSHIP_ATTN_TRACE_BUILD 0
 #endif
-template <int QT, int KS>
+// V = softmax bookkeeping variant (the loop is VALU-issue bound next to its MFMAs - 55 VALU + 17 transcendentals per 8 MFMAs in
+// V = 1 - while the matrix pipe idles three quarters of the time, so V >= 2 move VALU work INTO the matrix pipe):
+//   1  classic online softmax: exact running max m, P = exp2(s - m): 16 v_sub per (key tile, query tile), rescale when m moves;
+//   2  the reference exponent r rides in the QK^T MFMA chain: a fifth K-step whose A fragment is a column of ones and whose B
+//      fragment holds -r of the lane's query (fp16), so the accumulator comes out as s - r and P = exp2(acc) directly - no
+//      subtractions.  r is a per-query fp16 value close to the running max (softmax is shift invariant: any reference within
+//      fp16 range of the max is exact; P <= 2^8 stays far inside fp16).  r is set from the first key tile and moved only when
+//      a tile's maximum exceeds it by more than 8 (then this tile's scores are re-based in place: 16 v_sub in a rare branch);
+//      (a third variant with the row sums on the matrix pipe as well - l += ones(32 x 16) P, two more MFMAs per key tile instead of
+//      eight v_dot2_f32_f16 - measured no faster than 2 and sat on the mscores0 bar: profiles/r03_a_attention_variants.txt; removed).
+template <int QT, int KS, int V>
 __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                          const _Float16* __restrict__ vt, const int* __restrict__ lens,
                                                          int NP, int cross, _Float16* __restrict__ ctx,
-                                                         unsigned long long* __restrict__ trace) {
+                                                         unsigned long long* __restrict__ trace, int gx, int S) {
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
   if (SSHIP_ATTN_TRACE_BUILD && trace) tr0 = __builtin_readcyclecounter();
   // One workgroup = 32*QT queries of one (sequence, head); its 4 waves split the KEYS (tile kt -> wave kt & 3,
   // flash-decoding style) and merge their (m, l, O) partials through LDS.
   extern __shared__ __attribute__((aligned(16))) char smem_attn[];
   float (*s_part)[4][34][64] = reinterpret_cast<float (*)[4][34][64]>(smem_attn);  // [QT][wave][32 O regs + m + l][lane]
-  const int s = blockIdx.z, h = blockIdx.y;
+  // XCD-aware workgroup mapping.  The gx workgroups of one (sequence, head) stream the same K / V^T (and, in the cross block,
+  // the partner sequence's), 156 KB each - more than the launch's L2 footprint allows to stay resident (120 MB of Q / K / V^T per
+  // 64-pair launch against 8 x 4 MB of L2).  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, so with
+  // a plain (x, head, sequence) grid those gx workgroups land on gx DIFFERENT XCDs and every one of their private L2s fetches the
+  // same K / V^T over the fabric (400 MB per launch at 4.1 TB/s: a third of the wave cycles were s_waitcnt, profiles/r02_final_pmc_sq).
+  // The grid is therefore 1-D and id -> logical workgroup L = (id % 8) * ceil(N / 8) + id / 8: XCD k runs the CONSECUTIVE logical
+  // workgroups [k N/8, (k+1) N/8), i.e. all query blocks of a (sequence, head), then its other heads, then the partner sequence.
+  // (Placement is a speed assumption only: any mapping of ids to XCDs computes the same result.)
+  const int n_wg = gx * 4 * (S < 0 ? -S : S), per_xcd = (n_wg + 7) >> 3;
+  const int L = S < 0 ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);   // S < 0: identity mapping (A/B runs)
+  if (L >= n_wg) return;  // the grid is padded to a multiple of 8
+  const int bx = L % gx, h = (L / gx) & 3, s = L / (gx * 4);
+  (void)per_xcd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
   const int qgrp = wave / KS, ksp = wave % KS;
-  const int qt0 = (blockIdx.x * (4 / KS) + qgrp) * QT;  // first 32-query tile of this wave's query group
+  const int qt0 = (bx * (4 / KS) + qgrp) * QT;  // first 32-query tile of this wave's query group
   const int q0 = qt0 * 32;
   const int sk = cross ? (s ^ 1) : s;
   const int nq = min(max(lens[s], 0), NP), nk = min(max(lens[sk], 0), NP);  // device-side counts are clamped to capacity
-  if ((int)blockIdx.x * (4 / KS) * QT * 32 >= nq) return;  // uniform for the whole workgroup
+  if (bx * (4 / KS) * QT * 32 >= nq) return;  // uniform for the whole workgroup
   const bool active = q0 < nq && q0 < NP;  // wave-uniform: a query group past the end only takes part in the barrier
   // Q/K/V are stored in MFMA-fragment order per 32-token tile (EpiHeads): every operand load below is one
   // fully coalesced 1-KiB wave load (16 B per lane, lane-linear).
@@ -217,15 +239,27 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
         vf[kk][mt] = *reinterpret_cast<const h8_t*>(VT + (((size_t)ktc * 2 + kk) * 2 + mt) * 512 + lane * 8);
   };
   const h2_t ones2 = {(_Float16)1.f, (_Float16)1.f};
+  // V = 2: A fragment "column 0 = 1" (rows = keys; lane (row, hh) holds k = 8 hh + e) and, per query tile, the B fragment
+  // "row 0 = -r of the lane's query" (lane (query, hh) holds k = 8 hh + e); m[t] holds r.
+  h8_t ones_k0, rf[QT];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones_k0[e] = (_Float16)0.f;
+  if (hh == 0) ones_k0[0] = (_Float16)1.f;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rf[t][e] = (_Float16)0.f;
+    if (V >= 2) m[t] = 0.f;
+  }
   // one key tile for the QT query tiles of this wave
   auto tile = [&](const h8_t (&kf)[4], const h8_t (&vf)[2][2], int kt) __attribute__((always_inline)) {
     const int k0 = kt * 32;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f16x_t st = mfma32(kf[0], qf[t][0], zero16);
+      f16x_t st = V >= 2 ? mfma32(ones_k0, rf[t], zero16) : zero16;   // -r per query, or 0
 #pragma unroll
-      for (int ks = 1; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
+      for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
       if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
         int kb = k0 + 4 * hh;
         asm volatile("" : "+v"(kb));  // keeps the 16 key indices inside the branch (hipcc hoisted them into every iteration)
@@ -239,15 +273,33 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
       tmax = max3f(tmax, st[3], st[4]);
 #pragma unroll
       for (int r = 5; r < 15; r += 2) tmax = max3f(tmax, st[r], st[r + 1]);
-      const float m_new = max3f(m[t], st[15], max_xor32(max3f(tmax, st[15], st[15])));
-      // the softmax is VALU-bound at head_dim 64: rescale the 32 output accumulators only when some query's running
-      // max actually moved (exact - not the lossy defer-max trick)
-      if (__any(m_new > m[t])) {
-        const float alpha = __builtin_amdgcn_exp2f(m[t] - m_new);
-        l[t] *= alpha;
+      if constexpr (V == 1) {
+        const float m_new = max3f(m[t], st[15], max_xor32(max3f(tmax, st[15], st[15])));
+        // the softmax is VALU-bound at head_dim 64: rescale the 32 output accumulators only when some query's running
+        // max actually moved (exact - not the lossy defer-max trick)
+        if (__any(m_new > m[t])) {
+          const float alpha = __builtin_amdgcn_exp2f(m[t] - m_new);
+          l[t] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[t][0][r] *= alpha; o[t][1][r] *= alpha; }
-        m[t] = m_new;
+          for (int r = 0; r < 16; ++r) { o[t][0][r] *= alpha; o[t][1][r] *= alpha; }
+          m[t] = m_new;
+        }
+      } else {
+        // st = s - r.  First tile of this wave (l == 0 and nothing accumulated yet): r <- fp16(max); later: only when the tile's
+        // maximum exceeds r by more than 8.  Both halves of a query's lane pair see the same tmax, so they take the same decision.
+        tmax = max_xor32(max3f(tmax, st[15], st[15]));
+        const bool first = kt == ksp;
+        const bool need = first || tmax > 8.0f;
+        if (__any(need)) {
+          const float r_new = need ? (float)(_Float16)(m[t] + tmax) : m[t];   // fp16-representable, like every r
+          const float d = r_new - m[t];
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          l[t] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o[t][0][r] *= alpha; o[t][1][r] *= alpha; st[r] -= d; }
+          m[t] = r_new;
+          rf[t][0] = hh == 0 ? (_Float16)(-r_new) : (_Float16)0.f;
+        }
       }
       // P in fp16 (the PV operand); the row sum is taken over exactly these rounded values: v_dot2_f32_f16 against ones, fp32
       // accumulate - half the instructions of sixteen fp32 adds
@@ -257,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-          const h2_t pp = {(_Float16)__builtin_amdgcn_exp2f(st[8 * kk + e] - m[t]), (_Float16)__builtin_amdgcn_exp2f(st[8 * kk + e + 1] - m[t])};
+          const float a0 = V == 1 ? st[8 * kk + e] - m[t] : st[8 * kk + e], a1 = V == 1 ? st[8 * kk + e + 1] - m[t] : st[8 * kk + e + 1];
+          const h2_t pp = {(_Float16)__builtin_amdgcn_exp2f(a0), (_Float16)__builtin_amdgcn_exp2f(a1)};
           pb[kk][e] = pp[0]; pb[kk][e + 1] = pp[1];
           if (kk == 0) ls0 = __builtin_amdgcn_fdot2(pp, ones2, ls0, false);
           else ls1 = __builtin_amdgcn_fdot2(pp, ones2, ls1, false);
@@ -286,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     l[t] += __shfl_xor(l[t], 32, 64);
+    if (V >= 2 && ntiles <= ksp) m[t] = -INFINITY;   // a wave that saw no key tile contributes nothing to the merge
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s_part[t][wave][r][lane] = o[t][0][r]; s_part[t][wave][16 + r][lane] = o[t][1][r]; }
     s_part[t][wave][32][lane] = m[t];
@@ -325,23 +379,25 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     }
   }
   if (SSHIP_ATTN_TRACE_BUILD && trace && lane == 0) {
-    unsigned long long* o = trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+    unsigned long long* o = trace + ((size_t)L * 4 + wave) * 4;
     o[0] = tr1 - tr0; o[1] = tr2 - tr1; o[2] = __builtin_readcyclecounter() - tr2; o[3] = 1;
   }
 }
-template <int QT, int KS>
-static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
+template <int QT, int KS, int V>
+static void launch_attn_v(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                         _Float16* ctx, hipStream_t s) {
   constexpr size_t smem = (size_t)QT * 4 * 34 * 64 * sizeof(float);
   constexpr int QPB = 32 * QT * (4 / KS);  // queries per workgroup
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   (void)attr_rc;  // thread-safe one-time opt-in (magic static)
   unsigned long long* tbuf = nullptr;
   const size_t nwg = (size_t)((d.NP + QPB - 1) / QPB) * 4 * d.S;
   static const bool trace_on = SSHIP_ATTN_TRACE_BUILD && getenv("SSHIP_ATTN_TRACE") != nullptr;
   if (trace_on) { (void)hipMalloc(&tbuf, nwg * 16 * 8); (void)hipMemsetAsync(tbuf, 0, nwg * 16 * 8, s); }
-  hipLaunchKernelGGL((k_lg_attention<QT, KS>), dim3((d.NP + QPB - 1) / QPB, 4, d.S), dim3(256), smem, s, q, k, vt, lens, d.NP,
-                     cross ? 1 : 0, ctx, tbuf);
+  const int gx = (d.NP + QPB - 1) / QPB;
+  static const bool xcd_off = getenv("SUPERSLAM_HIP_ATTN_XCD") && atoi(getenv("SUPERSLAM_HIP_ATTN_XCD")) == 0;  // A/B: plain id order
+  hipLaunchKernelGGL((k_lg_attention<QT, KS, V>), dim3(((size_t)gx * 4 * d.S + 7) / 8 * 8), dim3(256), smem, s, q, k, vt, lens, d.NP,
+                     cross ? 1 : 0, ctx, tbuf, gx, xcd_off ? -d.S : d.S);
   if (trace_on) {
     std::vector<unsigned long long> h(nwg * 16);
     (void)hipStreamSynchronize(s);
@@ -353,6 +409,15 @@ static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt
                      (int)cross, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, cnt, nwg);
     (void)hipFree(tbuf);
   }
+}
+// softmax bookkeeping variant (see k_lg_attention): SUPERSLAM_HIP_ATTN_V = 1 | 2 (A/B runs); default kAttnV
+constexpr int kAttnV = 2;
+template <int QT, int KS>
+static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
+                        _Float16* ctx, hipStream_t s) {
+  static const int v_env = getenv("SUPERSLAM_HIP_ATTN_V") ? atoi(getenv("SUPERSLAM_HIP_ATTN_V")) : kAttnV;
+  if (v_env == 2) launch_attn_v<QT, KS, 2>(q, k, vt, lens, d, cross, ctx, s);
+  else launch_attn_v<QT, KS, 1>(q, k, vt, lens, d, cross, ctx, s);
 }
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                          _Float16* ctx, hipStream_t s, bool shared_gpu) {
