@@ -168,7 +168,8 @@ __device__ __forceinline__ float max_xor32(float x) {
 //      subtractions.  r is a per-query fp16 value close to the running max (softmax is shift invariant: any reference within
 //      fp16 range of the max is exact; P <= 2^8 stays far inside fp16).  r is set from the first key tile and moved only when
 //      a tile's maximum exceeds it by more than 8 (then this tile's scores are re-based in place: 16 v_sub in a rare branch);
-//      (a third variant with the row sums on the matrix pipe as well - l += ones(32 x 16) P, two more MFMAs per key tile instead of
+//   3  = 2 with the QK^T MFMA chains of both query tiles issued first and interleaved (see `tile`).
+//      (another variant with the row sums on the matrix pipe as well - l += ones(32 x 16) P, two more MFMAs per key tile instead of
 //      eight v_dot2_f32_f16 - measured no faster than 2 and sat on the mscores0 bar: profiles/r03_a_attention_variants.txt; removed).
 template <int QT, int KS, int V>
 __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
@@ -252,14 +253,30 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     if (V >= 2) m[t] = 0.f;
   }
   // one key tile for the QT query tiles of this wave
+  // V = 3: the QK^T chains of ALL query tiles are issued first, interleaved k-step by k-step (independent accumulators: no
+  // dependent-MFMA stall, and the second tile's MFMAs execute while the first tile's softmax VALU issues); V <= 2: tile by tile.
   auto tile = [&](const h8_t (&kf)[4], const h8_t (&vf)[2][2], int kt) __attribute__((always_inline)) {
     const int k0 = kt * 32;
+    const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16x_t stq[QT];
+    if constexpr (V == 3) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) stq[t] = mfma32(ones_k0, rf[t], zero16);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) stq[t] = mfma32(kf[ks], qf[t][ks], stq[t]);
+      __builtin_amdgcn_sched_barrier(0);  // the MFMAs above stay ahead of the first tile's softmax
+    }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f16x_t st = V >= 2 ? mfma32(ones_k0, rf[t], zero16) : zero16;   // -r per query, or 0
+      f16x_t st;
+      if constexpr (V == 3) st = stq[t];
+      else {
+        st = V >= 2 ? mfma32(ones_k0, rf[t], zero16) : zero16;   // -r per query, or 0
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
+        for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
+      }
       if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
         int kb = k0 + 4 * hh;
         asm volatile("" : "+v"(kb));  // keeps the 16 key indices inside the branch (hipcc hoisted them into every iteration)
@@ -410,185 +427,14 @@ static void launch_attn_v(const _Float16* q, const _Float16* k, const _Float16* 
     (void)hipFree(tbuf);
   }
 }
-// ---------------------------------------------------------------------------------------------------
-// Attention with the K / V^T tiles SHARED through an LDS ring (no key split; throughput batches under two streams).
-// In k_lg_attention every wave loads its own copy of every K / V^T fragment straight into registers, one key tile ahead: the
-// four waves of a workgroup (4 x QT x 32 = 256 queries of one (sequence, head)) fetch the same 8 KB per key tile four times,
-// and with ~2.4 k clocks of prefetch distance a third of the wave cycles were spent in s_waitcnt vmcnt (profiles/r03_c_pmc_sq).
-// Here a key tile (K: 4 fragments of 1 KiB, V^T: 4 fragments, contiguous in memory in fragment order) is brought in ONCE per
-// workgroup by LDS-DMA (global_load_lds_dwordx4: wave w moves fragments 2w and 2w+1, one M0 + an instruction offset) into a
-// ring of kRingSlots tiles, kRingSlots - 1 tiles ahead; one s_barrier per key tile says "tile kt has landed for everybody and
-// nobody reads tile kt - 1 any more", then every wave reads its fragments with lane-linear ds_read_b128 (conflict-free).
-// L2 -> CU traffic / 4, prefetch distance x3, 64 registers of K / V^T double buffers gone, no LDS merge of partials:
-// the normalised rows are written from the accumulators.
-// Softmax bookkeeping = variant 2 of k_lg_attention (reference exponent r in the QK^T MFMA chain).
-// ---------------------------------------------------------------------------------------------------
-constexpr int kRingSlots = 4;
-// WPS = waves per SIMD the register allocation is held to: 3 (168 VGPRs; the V^T fragments are then re-read from LDS per query
-// tile instead of being held across the softmax) puts three workgroups on a CU - a wave issues one VALU instruction per ~5 clocks
-// while the SIMD could retire one per 2, so a third wave per SIMD adds VALU issue, the resource this loop runs out of.
-template <int QT, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_lg_attention_ring(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
-                                                              const _Float16* __restrict__ vt, const int* __restrict__ lens,
-                                                              int NP, int cross, _Float16* __restrict__ ctx, int gx, int S) {
-  extern __shared__ __attribute__((aligned(16))) char smem_ring[];
-  _Float16* ring = reinterpret_cast<_Float16*>(smem_ring);  // [slot][fragment 0..3 = K k-steps, 4..7 = V^T (kk, mt)][512]
-  // XCD-aware mapping as in k_lg_attention: XCD k runs consecutive logical workgroups
-  const int n_wg = gx * 4 * S, per_xcd = (n_wg + 7) >> 3;
-  const int L = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (L >= n_wg) return;
-  const int bx = L % gx, h = (L / gx) & 3, s = L / (gx * 4);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const int qt0 = (bx * 4 + wave) * QT, q0 = qt0 * 32;
-  const int sk = cross ? (s ^ 1) : s;
-  const int nq = min(max(lens[s], 0), NP), nk = min(max(lens[sk], 0), NP);
-  if (bx * 4 * QT * 32 >= nq) return;  // uniform for the whole workgroup
-  const bool active = q0 < nq;         // wave-uniform: a wave past the end still loads its share of every tile and meets the barriers
-  const int nt32 = NP >> 5;
-  const _Float16* Q = q + ((size_t)(s * 4 + h) * nt32) * 2048;
-  const _Float16* K = k + ((size_t)(sk * 4 + h) * nt32) * 2048;
-  const _Float16* VT = vt + ((size_t)(sk * 4 + h) * nt32) * 2048;
-  h8_t qf[QT][4];
-#pragma unroll
-  for (int t = 0; t < QT; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)min(qt0 + t, nt32 - 1) * 4 + ks) * 512 + lane * 8);
-  const int ntiles = (nk + 31) >> 5;  // workgroup-uniform
-  // this wave's two fragments of key tile kt -> ring slot kt % kRingSlots.  Tiles past the end are clamped (a valid tile is
-  // re-read and never used) so that every wave always has the same number of DMAs in flight: the waits below are static counts.
-  const _Float16* my_src = (wave < 2 ? K : VT) + (wave & 1) * 1024 + lane * 8;
-  auto issue = [&](int kt) __attribute__((always_inline)) {
-    const _Float16* g = my_src + (size_t)min(kt, ntiles - 1) * 2048;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(ring + ((kt % kRingSlots) * 8 + 2 * wave) * 512));
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-  };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the Q fragments are in: from here on vmcnt counts ring DMAs only
-#pragma unroll
-  for (int p = 0; p < kRingSlots - 1; ++p) issue(p);
-
-  float r_ref[QT], l[QT];
-  f16x_t o[QT][2];
-  h8_t ones_k0, rf[QT];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones_k0[e] = (_Float16)0.f;
-  if (hh == 0) ones_k0[0] = (_Float16)1.f;
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    r_ref[t] = 0.f; l[t] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) rf[t][e] = (_Float16)0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[t][0][r] = 0.f; o[t][1][r] = 0.f; }
-  }
-  const h2_t ones2 = {(_Float16)1.f, (_Float16)1.f};
-#pragma unroll 1
-  for (int kt = 0; kt < ntiles; ++kt) {
-    // the oldest two of this wave's 2 (kRingSlots - 1) DMAs are tile kt's
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (kRingSlots - 2)) : "memory");
-    __syncthreads();             // tile kt is complete; every wave is done with tile kt - 1
-    issue(kt + kRingSlots - 1);  // ... whose slot takes the tile kRingSlots - 1 ahead
-    if (!active) continue;
-    const _Float16* slot = ring + (kt % kRingSlots) * 4096 + lane * 8;
-    h8_t kf[4], vf[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const h8_t*>(slot + ks * 512);
-    if constexpr (WPS < 3) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) vf[kk][mt] = *reinterpret_cast<const h8_t*>(slot + (4 + kk * 2 + mt) * 512);
-    }
-    const int k0 = kt * 32;
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-      const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f16x_t st = mfma32(ones_k0, rf[t], zero16);  // -r of the lane's query
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
-      if (k0 + 32 > nk) {  // ragged last key tile (wave-uniform)
-        int kb = k0 + 4 * hh;
-        asm volatile("" : "+v"(kb));
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kb + (r & 3) + 8 * (r >> 2) >= nk) st[r] = -INFINITY;
-      }
-      float tmax = max3f(st[0], st[1], st[2]);
-      tmax = max3f(tmax, st[3], st[4]);
-#pragma unroll
-      for (int r = 5; r < 15; r += 2) tmax = max3f(tmax, st[r], st[r + 1]);
-      tmax = max_xor32(max3f(tmax, st[15], st[15]));
-      const bool need = kt == 0 || tmax > 8.0f;
-      if (__any(need)) {
-        const float r_new = need ? (float)(_Float16)(r_ref[t] + tmax) : r_ref[t];
-        const float d = r_new - r_ref[t];
-        const float alpha = __builtin_amdgcn_exp2f(-d);
-        l[t] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[t][0][r] *= alpha; o[t][1][r] *= alpha; st[r] -= d; }
-        r_ref[t] = r_new;
-        rf[t][0] = hh == 0 ? (_Float16)(-r_new) : (_Float16)0.f;
-      }
-      float ls0 = 0.f, ls1 = 0.f;
-      h8_t pb[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const h2_t pp = {(_Float16)__builtin_amdgcn_exp2f(st[8 * kk + e]), (_Float16)__builtin_amdgcn_exp2f(st[8 * kk + e + 1])};
-          pb[kk][e] = pp[0]; pb[kk][e + 1] = pp[1];
-          if (kk == 0) ls0 = __builtin_amdgcn_fdot2(pp, ones2, ls0, false);
-          else ls1 = __builtin_amdgcn_fdot2(pp, ones2, ls1, false);
-        }
-      l[t] += ls0 + ls1;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          if constexpr (WPS >= 3) vf[kk][mt] = *reinterpret_cast<const h8_t*>(slot + (4 + kk * 2 + mt) * 512);
-          o[t][mt] = mfma32(vf[kk][mt], pb[kk], o[t][mt]);
-        }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing this workgroup's LDS when it exits
-  if (!active) return;
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    if (q0 + t * 32 >= nq) break;
-    const float lt = l[t] + __shfl_xor(l[t], 32, 64);
-    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
-    _Float16* orow = ctx + ((size_t)s * NP + q0 + t * 32 + j) * 256 + h * 64 + 4 * hh;
-    // register 4 g + e of M-tile mt is channel 32 mt + 8 g + 4 hh + e of the lane's query
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<h4_t*>(orow + mt * 32 + g * 8) =
-            to_h4(o[t][mt][4 * g] * inv, o[t][mt][4 * g + 1] * inv, o[t][mt][4 * g + 2] * inv, o[t][mt][4 * g + 3] * inv);
-  }
-}
-template <int QT, int WPS>
-static void launch_attn_ring(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
-                             _Float16* ctx, hipStream_t s) {
-  constexpr size_t smem = (size_t)kRingSlots * 8 * 512 * sizeof(_Float16);  // 32 KiB
-  constexpr int QPB = 32 * QT * 4;
-  const int gx = (d.NP + QPB - 1) / QPB;
-  hipLaunchKernelGGL((k_lg_attention_ring<QT, WPS>), dim3(((size_t)gx * 4 * d.S + 7) / 8 * 8), dim3(256), smem, s, q, k, vt, lens, d.NP,
-                     cross ? 1 : 0, ctx, gx, d.S);
-}
-
-// softmax bookkeeping variant (see k_lg_attention): SUPERSLAM_HIP_ATTN_V = 1 | 2 (A/B runs); default kAttnV
-constexpr int kAttnV = 2;
+// softmax bookkeeping variant (see k_lg_attention): SUPERSLAM_HIP_ATTN_V = 1 | 2 | 3 (A/B runs); default kAttnV
+constexpr int kAttnV = 3;
 template <int QT, int KS>
 static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                         _Float16* ctx, hipStream_t s) {
   static const int v_env = getenv("SUPERSLAM_HIP_ATTN_V") ? atoi(getenv("SUPERSLAM_HIP_ATTN_V")) : kAttnV;
-  if (v_env == 2) launch_attn_v<QT, KS, 2>(q, k, vt, lens, d, cross, ctx, s);
+  if (v_env == 3) launch_attn_v<QT, KS, 3>(q, k, vt, lens, d, cross, ctx, s);
+  else if (v_env == 2) launch_attn_v<QT, KS, 2>(q, k, vt, lens, d, cross, ctx, s);
   else launch_attn_v<QT, KS, 1>(q, k, vt, lens, d, cross, ctx, s);
 }
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
@@ -606,15 +452,6 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
     // round of a 256-query workgroup (no key split: no LDS merge, the prologue paid once per 19 key tiles) costs nothing:
     // 92 -> 101 us for a launch on its own, but -1.2 % on the two-stream LightGlue call
     const int ks = ks_env == 4 ? 4 : (ks_env == 1 || (ks_env == 0 && shared_gpu)) ? 1 : 2;
-    // no key split -> the LDS-ring kernel (K / V^T fetched once per workgroup); SUPERSLAM_HIP_ATTN_RING=0 keeps k_lg_attention<2,1>,
-    // =2 uses the ring kernel also for launches that have the GPU to themselves (A/B runs)
-    static const int ring_env = getenv("SUPERSLAM_HIP_ATTN_RING") ? atoi(getenv("SUPERSLAM_HIP_ATTN_RING")) : 1;
-    static const int wps_env = getenv("SUPERSLAM_HIP_ATTN_WPS") ? atoi(getenv("SUPERSLAM_HIP_ATTN_WPS")) : 2;   // 3: 168-VGPR build (A/B)
-    if (qt_env != 1 && ((ks == 1 && ring_env >= 1) || ring_env == 2)) {
-      if (wps_env == 3) launch_attn_ring<2, 3>(q, k, vt, lens, d, cross, ctx, s);
-      else launch_attn_ring<2, 2>(q, k, vt, lens, d, cross, ctx, s);
-      return;
-    }
     if (qt_env == 1) {
       if (ks == 4) launch_attn<1, 4>(q, k, vt, lens, d, cross, ctx, s);
       else if (ks == 1) launch_attn<1, 1>(q, k, vt, lens, d, cross, ctx, s);
