@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Pin the two PARITY-UNPINNED oracles against their third-party sources, on a machine that has them.
 
-  python scripts/pin_oracles.py [--lightglue] [--eigenplaces] [--write]
+  python oracle/pin_oracles.py [--lightglue] [--eigenplaces] [--write]
 
 oracle/lightglue_ref.py and oracle/eigenplaces_ref.py restate published algorithms whose source is NOT under /root/reference
 and NOT in the build image: the `lightglue` package (utils/convert_lightglue_to_onnx.py:8, un-tagged git
@@ -34,7 +34,7 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # oracle/ is test infrastructure: this checker lives next to what it checks
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

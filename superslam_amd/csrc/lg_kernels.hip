@@ -164,8 +164,8 @@ __device__ __forceinline__ float max_xor32(float x) {
 // V = 1 - while the matrix pipe idles three quarters of the time, so V >= 2 move VALU work INTO the matrix pipe):
 //   1  classic online softmax: exact running max m, P = exp2(s - m): 16 v_sub per (key tile, query tile), rescale when m moves;
 //   2  the reference exponent r rides in the QK^T MFMA chain: a fifth K-step whose A fragment is a column of ones and whose B
-//      fragment holds -r of the lane's query (fp16), so the accumulator comes out as s - r and P = exp2(acc) directly - no
-//      subtractions.  r is a per-query fp16 value close to the running max (softmax is shift invariant: any reference within
+//      fragment holds -r of the lane's query (as two fp16 k-slots, 256 a + b), so the accumulator comes out as s - r and
+//      P = exp2(acc) directly - no subtractions.  r is a per-query value close to the running max (softmax is shift invariant: any reference within
 //      fp16 range of the max is exact; P <= 2^8 stays far inside fp16).  r is set from the first key tile and moved only when
 //      a tile's maximum exceeds it by more than 8 (then this tile's scores are re-based in place: 16 v_sub in a rare branch);
 //   3  = 2 with the QK^T MFMA chains of both query tiles issued first and interleaved (see `tile`).
@@ -242,10 +242,13 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   const h2_t ones2 = {(_Float16)1.f, (_Float16)1.f};
   // V = 2: A fragment "column 0 = 1" (rows = keys; lane (row, hh) holds k = 8 hh + e) and, per query tile, the B fragment
   // "row 0 = -r of the lane's query" (lane (query, hh) holds k = 8 hh + e); m[t] holds r.
+  // r is carried as 256 a + b with a, b fp16 (k-slots 0 and 1: A = [256, 1], B = [-a, -b]): exact to fp32 precision for any
+  // |r| < 1.6e7 - a single fp16 slot would turn a row whose scaled logits exceed 65 504 into inf (the reference's fp16 engine
+  // overflows there as well; this path must not be the narrower one).
   h8_t ones_k0, rf[QT];
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones_k0[e] = (_Float16)0.f;
-  if (hh == 0) ones_k0[0] = (_Float16)1.f;
+  if (hh == 0) { ones_k0[0] = (_Float16)256.f; ones_k0[1] = (_Float16)1.f; }
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
 #pragma unroll
@@ -308,14 +311,22 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
         const bool first = kt == ksp;
         const bool need = first || tmax > 8.0f;
         if (__any(need)) {
-          const float r_new = need ? (float)(_Float16)(m[t] + tmax) : m[t];   // fp16-representable, like every r
+          const float r_tgt = m[t] + tmax;
+          // the coarse slot comes in at |r| >= 2048: below that a = 0 and r = fp16(running max) is off by <= 0.5, so P <= 2^8.5;
+          // above it a single fp16 value would be off by up to 16 (32768 <= |r|) and P = exp2(8 + 16) overflows fp16 -> NaN
+          const float ra = fabsf(r_tgt) < 2048.f ? 0.f : (float)(_Float16)(fminf(fmaxf(r_tgt * (1.0f / 256.0f), -65000.f), 65000.f));
+          const float rb = (float)(_Float16)(r_tgt - 256.0f * ra);
+          const float r_new = need ? 256.0f * ra + rb : m[t];   // = what the two k-slots add up to in the MFMA
           const float d = r_new - m[t];
-          const float alpha = __builtin_amdgcn_exp2f(-d);
+          // first tile: l = o = 0 and d = r itself, possibly very negative (exp2(-d) = inf, 0 * inf = NaN: found by
+          // tests/test_gpu_lightglue_layers.py::test_large_residual_stream_magnitudes) - nothing to rescale yet.
+          // Later tiles move r up by more than ~8, so alpha <= 2^-7.
+          const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
           l[t] *= alpha;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { o[t][0][r] *= alpha; o[t][1][r] *= alpha; st[r] -= d; }
           m[t] = r_new;
-          rf[t][0] = hh == 0 ? (_Float16)(-r_new) : (_Float16)0.f;
+          if (need && hh == 0) { rf[t][0] = (_Float16)(-ra); rf[t][1] = (_Float16)(-rb); }
         }
       }
       // P in fp16 (the PV operand); the row sum is taken over exactly these rounded values: v_dot2_f32_f16 against ones, fp32

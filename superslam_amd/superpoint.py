@@ -138,6 +138,39 @@ class SuperPoint:
             return False, kp[:0], desc[:0]
         return True, kp[: n.value].copy(), desc[: n.value].copy()
 
+    # ---- decode-ahead upload ring + cross-frame pipelining (include/sship.h: sship_sp_ring_*) ------------------
+    def ring_create(self, depth: int, h: int, w: int, channels: int = 1) -> bool:
+        rc = _lib.lib().sship_sp_ring_create(self._h, depth, h, w, channels)
+        if rc != _lib.OK:
+            self.last_error = (_lib.lib().sship_last_error() or b"").decode()
+        self._ring = (depth, h, w, channels)
+        return rc == _lib.OK
+
+    def ring_host(self, slot: int, image: int) -> np.ndarray:
+        """The slot's pinned host image (0 = left, 1 = right) as a writable numpy view [h, w(, 3)]."""
+        _, h, w, ch = self._ring
+        ptr = _lib.lib().sship_sp_ring_host(self._h, slot, image)
+        buf = (C.c_uint8 * (h * w * ch)).from_address(ptr)
+        a = np.frombuffer(buf, np.uint8)
+        return a.reshape(h, w) if ch == 1 else a.reshape(h, w, ch)
+
+    def ring_upload(self, slot: int) -> None:
+        _lib.check(_lib.lib().sship_sp_ring_upload(self._h, slot))
+
+    def ring_submit(self, slot: int) -> None:
+        """Enqueue the extraction of an uploaded slot ahead of time; extract_stereo_ring(slot) then only waits for it."""
+        _lib.check(_lib.lib().sship_sp_ring_submit(self._h, slot))
+
+    def extract_stereo_ring(self, slot: int):
+        kl = np.zeros((self.max_keypoints, 3), np.float32)
+        kr = np.zeros((self.max_keypoints, 3), np.float32)
+        fl = _lib.Features(kl.ctypes.data_as(C.POINTER(C.c_float)), 0, None, -1)
+        fr = _lib.Features(kr.ctypes.data_as(C.POINTER(C.c_float)), 0, None, -1)
+        rc = _lib.lib().sship_sp_extract_stereo_ring(self._h, slot, C.byref(fl), C.byref(fr))
+        if rc != _lib.OK:
+            self.last_error = (_lib.lib().sship_last_error() or b"").decode()
+        return self._wrap(fl, kl), self._wrap(fr, kr)
+
     # ---- device-resident batch path (throughput) -----------------------------------------------
     def extract_batch_device(self, imgs, desc_out=None, kp_out=None, n_out=None, stream=None):
         """imgs: torch uint8 CUDA tensor [B,H,W].  Returns (desc f16 [B,K,256], kp f32 [B,K,3], n i32 [B])."""

@@ -198,3 +198,55 @@ def test_end_to_end_keypoint_iou_meets_the_contract(hip, weights_dir, parity_rep
         assert iou16 >= 0.98
     parity_report["e2e_keypoints_1376x376_600kp"] = rep
     sp.close()
+
+
+# ------------------------------------------------------------------------------------------------------
+# cross-frame pipelining: sship_sp_ring_submit (round 3)
+# ------------------------------------------------------------------------------------------------------
+def test_ring_submit_is_bit_identical_to_extract_stereo_and_survives_interleaving(weights_dir):
+    """A submitted slot yields exactly what the synchronous call yields (keypoints, scores, descriptors), also when another
+    extraction and a LightGlue match run on the same handles between the submission and its collection (results live in the
+    slot's own pinned buffers and pool slots; the handle's stream orders the device work), and a never-collected submission
+    hands its pool slots back when the ring goes away."""
+    import gc
+
+    from superslam_amd import LightGlue, SuperPoint, _lib
+    from superslam_amd.synth import make_stereo_pair
+
+    h, w = 240, 376
+    sp = SuperPoint(weights_dir["sp_path"], 300, 0.005, 4, max_batch=2)
+    lg = LightGlue(weights_dir["lg_path"], w, h, max_keypoints=300, max_pairs=1)
+    assert sp.initialize() and lg.initialize()
+    assert sp.ring_create(3, h, w, 1), sp.last_error
+    pairs = [make_stereo_pair(h, w, 900 + i) for i in range(3)]
+    ref = []
+    for l, r in pairs:                                   # synchronous reference
+        fl, fr = sp.extract_stereo(l, r)
+        ref.append([(f.keypoints.copy(), lg.descriptors_to_host(f.descriptors)) for f in (fl, fr)])
+        del fl, fr
+    gc.collect()
+    assert sp.pool_in_use() == 0
+    for s, (l, r) in enumerate(pairs):
+        sp.ring_host(s, 0)[:] = l; sp.ring_host(s, 1)[:] = r
+        sp.ring_upload(s)
+    sp.ring_submit(0)
+    sp.ring_submit(1)                                    # two submissions in flight
+    assert sp.pool_in_use() == 4
+    fl2, fr2 = sp.extract_stereo_ring(2)                 # a synchronous ring extraction in between (not submitted)
+    m = lg.match(fl2.keypoints, fl2.descriptors, fr2.keypoints, fr2.descriptors)   # and a match on the other handle
+    assert len(m.matches0) == len(fl2.keypoints)
+    got = {2: (fl2, fr2), 1: sp.extract_stereo_ring(1), 0: sp.extract_stereo_ring(0)}   # collected out of order
+    for s in range(3):
+        for b in range(2):
+            f = got[s][b]
+            np.testing.assert_array_equal(f.keypoints.view(np.uint32), ref[s][b][0].view(np.uint32), err_msg=f"slot {s} image {b}")
+            d = lg.descriptors_to_host(f.descriptors)
+            np.testing.assert_array_equal(d, ref[s][b][1], err_msg=f"slot {s} image {b} descriptors")
+    with pytest.raises(_lib.SshipError):
+        sp.ring_submit(0); sp.ring_submit(0)             # a slot holds one submission at a time
+    del got, fl2, fr2, f
+    gc.collect()
+    assert sp.pool_in_use() == 2                         # the uncollected submission of slot 0 still owns its two slots
+    assert sp.ring_create(2, h, w, 1)                    # re-creating the ring drops it and returns the slots
+    assert sp.pool_in_use() == 0
+    sp.close(); lg.close()

@@ -114,7 +114,8 @@ def test_normalize_keypoints_host_and_device_bit_exact(hip, weights_dir, golden_
 # ------------------------------------------------------------------------------------------------------
 # a14: residual stream and assignment similarity, layer by layer
 # ------------------------------------------------------------------------------------------------------
-def _check_layers(m, weights_dir, px0, d0, px1, d1, tag, parity_report, layers=(1, 5, 9), it=None, golden=None):
+def _check_layers(m, weights_dir, px0, d0, px1, d1, tag, parity_report, layers=(1, 5, 9), it=None, golden=None, x_abs_bar=X_ABS_BAR,
+                  x_rel_bar=X_REL_BAR, sim_rel_bar=SIM_REL_BAR):
     n0, n1 = len(px0), len(px1)
     if it is None:
         _, _, it = _oracle(weights_dir, px0, d0, px1, d1)
@@ -129,7 +130,8 @@ def _check_layers(m, weights_dir, px0, d0, px1, d1, tag, parity_report, layers=(
             mx = np.abs(got - ref).max()
             worst = max(worst, rel)
             print(f"LG layers {tag}: after layer {nl} seq {seq}: rel {rel:.2e} max|d| {mx:.2e} (|x| max {np.abs(ref).max():.2f})")
-            assert rel <= X_REL_BAR and mx <= X_ABS_BAR * max(1.0, np.abs(ref).max()), (tag, nl, seq, rel, mx)
+            assert np.isfinite(got).all(), (tag, nl, seq, "non-finite residual stream")
+            assert rel <= x_rel_bar and mx <= x_abs_bar * max(1.0, np.abs(ref).max()), (tag, nl, seq, rel, mx)
             if golden is not None and nl in (1, 9):   # the committed fixture holds layers 0 and 8
                 gref = golden[f"{tag}_x{seq}_l{nl - 1}"]
                 assert np.linalg.norm(got - gref) / np.linalg.norm(gref) <= X_REL_BAR
@@ -139,7 +141,7 @@ def _check_layers(m, weights_dir, px0, d0, px1, d1, tag, parity_report, layers=(
     sref = it["sim"][0].double().numpy()
     srel = np.abs(sim - sref).max() / np.abs(sref).max()
     print(f"LG layers {tag}: sim max|d| {np.abs(sim - sref).max():.3e} / max|sim| {np.abs(sref).max():.1f} = {srel:.2e}")
-    assert srel <= SIM_REL_BAR
+    assert np.isfinite(sim).all() and srel <= sim_rel_bar
     parity_report[f"lg_layers_{tag}"] = {"x_rel_worst": float(worst), "sim_rel": float(srel)}
     return res
 
@@ -344,3 +346,46 @@ def test_throughput_batch_kernels_match_latency_kernels(hip, lg, weights_dir, pa
     assert rel <= X_REL_BAR
     _lgcmp.check(_lgcmp.compare(m0[p], ms0[p], m_ref, s_ref))
     big.close()
+
+
+# ------------------------------------------------------------------------------------------------------
+# fp16 residual-stream headroom (VERDICT r02 "What's weak" 11): the published checkpoint cannot be loaded here, so the
+# seeded weights are scaled until the residual stream is 70x .. 1000x larger than in the other tests (|x| up to ~45, ~170,
+# ~670 after nine layers; fp16 tops out at 65 504) with the q / k gains scaled down by the same factor (attention logits
+# stay O(40), as a trained matcher's do), and the same layer-by-layer comparison with the fp64 oracle must hold.
+# The fourth case leaves the gains alone: scaled attention logits reach 8e4, beyond fp16's range (the reference's fp16 engine
+# would already have overflowed in QK^T).  fp16 q / k (relative precision 5e-4) then carry an absolute logit error of ~40,
+# the softmax is one-hot and flips between near-equal keys, so the fp64 oracle is no yardstick for single elements - what is
+# asserted is that nothing becomes inf / NaN (the reference exponent of the attention kernel takes its two-slot form
+# r = 256 a + b above |r| = 2048; a single fp16 r is off by up to 16 there and P = exp2(8 + 16) overflowed: found by this
+# test - as was exp2(-r) = inf on a wave's first key tile when r < -128) and that the stream stays within 5 % of the oracle after
+# the first layer.
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("residual_gain,assign_gain,qk_scale,strict", [(4.0, 0.5, 1 / 40, True), (16.0, 0.12, 1 / 160, True),
+                                                                      (64.0, 0.03, 1 / 700, True), (4.0, 0.5, 1.0, False)])
+def test_large_residual_stream_magnitudes(hip, tmp_path, parity_report, residual_gain, assign_gain, qk_scale, strict):
+    from superslam_amd import LightGlue
+    from superslam_amd.weights import LG_CROSS_QK_GAIN, LG_SELF_QK_GAIN, make_lightglue_weights, save_safetensors
+
+    sd = make_lightglue_weights(1, residual_gain=residual_gain, assign_gain=assign_gain,
+                                self_qk_gain=tuple(v * qk_scale for v in LG_SELF_QK_GAIN),
+                                cross_qk_gain=tuple(v * qk_scale for v in LG_CROSS_QK_GAIN))
+    path = str(tmp_path / "lg_big.safetensors")
+    save_safetensors(sd, path)
+    m = LightGlue(path, W, HH, max_keypoints=160)
+    assert m.initialize(), m.last_error
+    k0, d0, k1, d1 = _random_sets(97, 130, 5)
+    px0, px1 = _px(k0), _px(k1)
+    m_ref, _, it = _oracle({"lg": sd}, px0, d0, px1, d1)
+    xmax = float(it["x0_layers"][8].abs().max())
+    tag = f"big_rg{int(residual_gain)}" + ("" if qk_scale < 1 else "_logits_beyond_fp16")
+    # beyond the fp16 domain the error compounds chaotically with depth (rel 0.5 after five layers, for the classic softmax kernel
+    # as well): the oracle is compared after the first layer only, everything after it must merely stay finite
+    bars = {} if strict else {"x_abs_bar": 1.0, "x_rel_bar": 5e-2, "sim_rel_bar": float("inf"), "layers": (1,)}
+    res = _check_layers(m, {"lg": sd}, px0, d0, px1, d1, tag, parity_report, it=it, **bars)
+    assert np.isfinite(res.mscores0).all() and (res.mscores0 >= 0).all() and (res.mscores0 <= 1.0 + 1e-6).all()
+    agree = float((res.matches0 == m_ref).mean())
+    print(f"LG {tag}: |x| max after layer 9 = {xmax:.1f}, matches0 agreement {agree:.4f}")
+    parity_report[f"lg_layers_{tag}"].update({"x_abs_max": xmax, "matches0_agreement": agree})
+    assert xmax > 40.0 and (agree >= 0.97 or not strict)
+    m.close()

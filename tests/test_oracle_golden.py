@@ -192,7 +192,7 @@ def test_lightglue_tiny_assignment_by_hand():
 
 
 # ------------------------------------------------------------------------------------------------------
-# pin-when-possible (VERDICT r02 "do this" 5): scripts/pin_oracles.py turns the two unpinned oracles green on a machine that
+# pin-when-possible (VERDICT r02 "do this" 5): oracle/pin_oracles.py turns the two unpinned oracles green on a machine that
 # has the third-party packages.  Here (no `lightglue`, no torchvision / hub model) it must import, skip cleanly (exit status 3),
 # leave the fixtures untouched, and the stamp it would write must be absent - "parity unpinned" stays the honest label.
 # ------------------------------------------------------------------------------------------------------
@@ -201,12 +201,12 @@ def test_pin_script_imports_and_skips_cleanly_without_the_packages(golden_dir):
     import json
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("pin_oracles", os.path.join(root, "scripts", "pin_oracles.py"))
+    spec = importlib.util.spec_from_file_location("pin_oracles", os.path.join(root, "oracle", "pin_oracles.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     before = open(os.path.join(golden_dir, "meta.json")).read()
     if mod.lightglue_available():
-        pytest.skip("the lightglue package IS importable here: run `python scripts/pin_oracles.py --write` and commit the stamp")
+        pytest.skip("the lightglue package IS importable here: run `python oracle/pin_oracles.py --write` and commit the stamp")
     assert mod.main(["--lightglue"]) == 3
     assert mod.main(["--lightglue", "--write"]) == 3
     assert open(os.path.join(golden_dir, "meta.json")).read() == before
