@@ -20,6 +20,8 @@ Prints ONE JSON line with the driver's fields plus
   roofline_mfma : the same for every matrix-core stage (conv layers in-situ + isolated, LightGlue stages isolated)
   roofline_hbm  : achieved GB/s against 8 TB/s for the memory-bound stages (NMS tile kernel, convPb, descriptor head /
                   gather, assignment passes), algorithmic bytes stated per entry
+  single_pair_protocol : BASELINE.md's protocol to the letter on the per-frame unit (50 warm-up + 500 timed pairs, one pair per call,
+                  median and p95 from device events); latency_ms_single_pair = median of five 50-call blocks of the same unit
   n1024         : the same metric with 1024 keypoints per image (the reference engine's upper profile)
   end_to_end    : the same step with the u8 images uploaded from pinned host memory (double buffered) and keypoints /
                   matches copied back inside the timed region (PCIe-inclusive; never `value`)
@@ -341,7 +343,11 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     torch.cuda.synchronize()
     call_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(40))
     out["call_ms"] = {"calls": 40, "pairs_per_call": P, "median": round(call_ms[20], 4), "p95": round(call_ms[37], 4),
-                      "min": round(call_ms[0], 4), "max": round(call_ms[-1], 4)}
+                      "min": round(call_ms[0], 4), "max": round(call_ms[-1], 4),
+                      "note": "BASELINE.md / SURVEY 8(d) config 2 asks for 50 warm-up + 500 timed PAIRS with median and p95; the unit timed here is a "
+                              f"library CALL of {P} pairs (device events between calls, no host synchronisation): {40 * P} timed pairs after "
+                              f"{args.warmup * CH * P + args.steps * CH * P} pairs of warm-up + headline steps; per-pair figures are these divided by {P}; "
+                              "the single-pair unit itself is `latency_ms_single_pair` (median of five 50-call blocks)"}
 
     lat_probe("after_call_ms")
     # ---- per-stage device time (hipEvents inside the library): IN-SITU launch durations of profiled headline calls ----
@@ -588,6 +594,21 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     blocks.sort()
     out["latency_ms_single_pair"] = round(blocks[2], 4)
     out["latency_ms_single_pair_blocks"] = [round(b, 4) for b in blocks]
+    # BASELINE.md / SURVEY 8(d) config 2 to the letter, on the per-frame unit: 50 warm-up pairs + 500 timed pairs, one pair per call,
+    # device events around every call (no host synchronisation inside the series), median and p95 per pair
+    for _ in range(50):
+        fe1.run(base[:2], stream)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(501)]
+    evs[0].record()
+    for i in range(500):
+        fe1.run(base[:2], stream)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(500))
+    out["single_pair_protocol"] = {"warmup_pairs": 50, "timed_pairs": 500, "median_ms": round(per[250], 4), "p95_ms": round(per[474], 4),
+                                   "pairs_per_s_at_median": round(1e3 / per[250], 1),
+                                   "unit": "one 1376x376 stereo pair per library call (SuperPoint batch 2 + select + descriptor head + 1x LightGlue), "
+                                           "device-resident, back to back on one stream"}
 
     # ---- the unit the reference actually runs per frame: the stereo match PLUS a second LightGlue call
     # against the previous keyframe (VoEstimator.cc:243).  Emulated with left(p) vs left(p+1) on the features of the call
