@@ -508,6 +508,9 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
               P * (2 * 2 * n * 256 * 2 + 4 * n * 4),
               "final projections of both images [n,256] fp16 read once per pass + match vectors, per pair (matrix-pipe / VALU bound)",
               P * 2 * ((n + 31) // 32 + 4) * n * 256 * 2)
+    # the assignment recomputes its similarity tiles on the matrix pipe instead of streaming a stored matrix: its bound is the
+    # matrix pipe + VALU (it is priced in roofline_mfma as lg_assign_pass1 / pass2); the entry above is kept for its byte counts
+    hbm[-1]["bound"] = "mfma+valu (by design: 11x the algorithmic bytes are re-read from L2 instead of a 92 MB fp32 matrix going through HBM four times)"
     out["roofline_hbm"] = hbm
 
     lat_probe("after_hbm_stages")
