@@ -26,6 +26,12 @@ __global__ __launch_bounds__((MODE >= 6 ? 512 : 1024)) void k(unsigned long long
   const int lane = threadIdx.x & 63;
   h8 a, b, a2, b2;
   for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.01f * (lane + e)); b[e] = (_Float16)(0.02f * (lane - e)); a2[e] = (_Float16)(0.03f * (lane + 2 * e)); b2[e] = (_Float16)(0.015f * (lane - 3 * e)); }
+  if (share < 0) {  // random operands in [-0.25, 0.25): every mantissa bit toggles, as with real descriptors (the constants above leave the datapath cold)
+    share = -share;
+    unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 12345u);
+    auto rnd = [&]() { h = h * 1664525u + 1013904223u; return (_Float16)(((int)(h >> 8) & 0xffff) * (0.5f / 65536.f) - 0.25f); };
+    for (int e = 0; e < 8; ++e) { a[e] = rnd(); b[e] = rnd(); a2[e] = rnd(); b2[e] = rnd(); }
+  }
   f16v c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
   float x[16];
   for (int i = 0; i < 16; ++i) x[i] = 0.001f * (lane + i);
@@ -190,7 +196,8 @@ static void run(const char* name, unsigned long long* d, float* sink, int share 
 int main() {
   unsigned long long* d; float* sink;
   hipMalloc(&d, 256 * 16 * 8); hipMalloc(&sink, 64);
-  hipMalloc(&kvbuf, (size_t)1024 * 19 * 4096 * 2 + 65536); hipMemset(kvbuf, 0x3c, (size_t)1024 * 19 * 4096 * 2 + 65536);
+  const size_t kvn = (size_t)1024 * 19 * 4096 + 32768;
+  hipMalloc(&kvbuf, kvn * 2); hipMemset(kvbuf, 0x3c, kvn * 2);
   run<0>("0 mfma x16", d, sink);
   run<1>("1 valu x128", d, sink);
   run<2>("2 mfma x16 | valu x128", d, sink);
@@ -201,5 +208,14 @@ int main() {
   run<7>("7 = 6 + vote / rescale (x2)", d, sink);
   run<8>("8 = 7 + ragged / first (x2)", d, sink);
   run<8>("8, no sharing across WGs", d, sink, 1);
+  {  // the same loops on random operands: what the DVFS power limit takes
+    std::vector<_Float16> hkv(kvn);
+    unsigned h = 1;
+    for (size_t i = 0; i < kvn; ++i) { h = h * 1664525u + 1013904223u; hkv[i] = (_Float16)(((int)(h >> 8) & 0xffff) * (0.5f / 65536.f) - 0.25f); }
+    hipMemcpy(kvbuf, hkv.data(), kvn * 2, hipMemcpyHostToDevice);
+    run<0>("0 mfma x16, random", d, sink, -5);
+    run<5>("5, random operands", d, sink, -5);
+    run<8>("8, random operands", d, sink, -5);
+  }
   return 0;
 }

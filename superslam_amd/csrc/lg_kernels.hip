@@ -160,6 +160,9 @@ __device__ __forceinline__ float max_xor32(float x) {
 #ifndef SSHIP_ATTN_TRACE_BUILD
 #define SSHIP_ATTN_TRACE_BUILD 0
 #endif
+#ifndef SSHIP_ATTN_REGFIN
+#define SSHIP_ATTN_REGFIN 1  // KS == 1: normalise and store the context straight from the accumulators (0: through the merge buffer, A/B builds)
+#endif
 // V = softmax bookkeeping variant (the loop is VALU-issue bound next to its MFMAs - 55 VALU + 17 transcendentals per 8 MFMAs in
 // V = 1 - while the matrix pipe idles three quarters of the time, so V >= 2 move VALU work INTO the matrix pipe):
 //   1  classic online softmax: exact running max m, P = exp2(s - m): 16 v_sub per (key tile, query tile), rescale when m moves;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)(active ? min(qt0 + t, nt32 - 1) : 0) * 4 + ks) * 512 + lane * 8);  // NP is a multiple of 32, not of 32 QT
+      qf[t][ks] = *reinterpret_cast<const h8_t*>(Q + ((size_t)min(qt0 + t, nt32 - 1) * 4 + ks) * 512 + lane * 8);  // NP is a multiple of 32, not of 32 QT; the address does not wait for `lens`
   float m[QT], l[QT];
   f16x_t o[QT][2];
 #pragma unroll
@@ -363,6 +366,30 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     }
   }
   if (SSHIP_ATTN_TRACE_BUILD && trace) tr2 = __builtin_readcyclecounter();
+  if constexpr (KS == 1 && SSHIP_ATTN_REGFIN) {
+    // no key split: nothing to merge - every lane normalises and stores its own accumulators (same values, same stores as the
+    // merge path below with one partial: 0 + o * 1 * inv), without the 68 LDS writes, the barrier that made a workgroup's waves
+    // wait for its slowest one, and the 66 LDS reads per lane.
+    if (!active) return;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (q0 + t * 32 >= nq) break;
+      const float lt = l[t] + __shfl_xor(l[t], 32, 64);
+      const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+      _Float16* orow = ctx + ((size_t)s * NP + q0 + t * 32 + j) * 256 + h * 64;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<h4_t*>(orow + mt * 32 + 8 * g + 4 * hh) =
+              to_h4(o[t][mt][4 * g] * inv, o[t][mt][4 * g + 1] * inv, o[t][mt][4 * g + 2] * inv, o[t][mt][4 * g + 3] * inv);
+    }
+    if (SSHIP_ATTN_TRACE_BUILD && trace && lane == 0) {
+      unsigned long long* o_ = trace + ((size_t)L * 4 + wave) * 4;
+      o_[0] = tr1 - tr0; o_[1] = tr2 - tr1; o_[2] = __builtin_readcyclecounter() - tr2; o_[3] = 1;
+    }
+    return;
+  }
   // ---- merge the KS key-partials of every query group ----
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -414,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 template <int QT, int KS, int V>
 static void launch_attn_v(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                         _Float16* ctx, hipStream_t s) {
-  constexpr size_t smem = (size_t)QT * 4 * 34 * 64 * sizeof(float);
+  constexpr size_t smem = KS == 1 && SSHIP_ATTN_REGFIN ? 0 : (size_t)QT * 4 * 34 * 64 * sizeof(float);
   constexpr int QPB = 32 * QT * (4 / KS);  // queries per workgroup
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   (void)attr_rc;  // thread-safe one-time opt-in (magic static)
