@@ -193,19 +193,26 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   // The grid is therefore 1-D and id -> logical workgroup L = (id % 8) * ceil(N / 8) + id / 8: XCD k runs the CONSECUTIVE logical
   // workgroups [k N/8, (k+1) N/8), i.e. all query blocks of a (sequence, head), then its other heads, then the partner sequence.
   // (Placement is a speed assumption only: any mapping of ids to XCDs computes the same result.)
-  const int n_wg = gx * 4 * (S < 0 ? -S : S), per_xcd = (n_wg + 7) >> 3;
+  // Without a key split (KS == 1, register finalisation) the four waves of a workgroup share nothing - no LDS, no barrier - so
+  // the unit of work is the WAVE: gx then counts the QT-tile query units of one (sequence, head) and wave W = 4 L + wave takes
+  // unit W % gx of (sequence, head) W / gx.  600 keypoints are 19 query tiles = 10 units: 640 full workgroups per 64 sequences
+  // instead of 768 of which every third ran 1.5 of its 4 waves.
+  constexpr bool kWaveUnits = KS == 1 && SSHIP_ATTN_REGFIN;
+  const int n_wg = (kWaveUnits ? gx : gx * 4) * (S < 0 ? -S : S), per_xcd = (n_wg + 7) >> 3;
   const int L = S < 0 ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);   // S < 0: identity mapping (A/B runs)
   if (L >= n_wg) return;  // the grid is padded to a multiple of 8
-  const int bx = L % gx, h = (L / gx) & 3, s = L / (gx * 4);
   (void)per_xcd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
   const int qgrp = wave / KS, ksp = wave % KS;
-  const int qt0 = (bx * (4 / KS) + qgrp) * QT;  // first 32-query tile of this wave's query group
+  const int W = L * 4 + wave;
+  const int bx = kWaveUnits ? W % gx : L % gx, h = kWaveUnits ? (W / gx) & 3 : (L / gx) & 3, s = kWaveUnits ? W / (gx * 4) : L / (gx * 4);
+  const int qt0 = kWaveUnits ? bx * QT : (bx * (4 / KS) + qgrp) * QT;  // first 32-query tile of this wave's query group
   const int q0 = qt0 * 32;
   const int sk = cross ? (s ^ 1) : s;
   const int nq = min(max(lens[s], 0), NP), nk = min(max(lens[sk], 0), NP);  // device-side counts are clamped to capacity
-  if (bx * (4 / KS) * QT * 32 >= nq) return;  // uniform for the whole workgroup
+  if (!kWaveUnits && bx * (4 / KS) * QT * 32 >= nq) return;  // uniform for the whole workgroup
   const bool active = q0 < nq && q0 < NP;  // wave-uniform: a query group past the end only takes part in the barrier
+  if (kWaveUnits && !active) return;       // ... and there is no barrier on this path
   // Q/K/V are stored in MFMA-fragment order per 32-token tile (EpiHeads): every operand load below is one
   // fully coalesced 1-KiB wave load (16 B per lane, lane-linear).
   const int nt32 = NP >> 5;
@@ -446,12 +453,13 @@ static void launch_attn_v(const _Float16* q, const _Float16* k, const _Float16* 
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   (void)attr_rc;  // thread-safe one-time opt-in (magic static)
   unsigned long long* tbuf = nullptr;
-  const size_t nwg = (size_t)((d.NP + QPB - 1) / QPB) * 4 * d.S;
+  constexpr bool kWaveUnits = KS == 1 && SSHIP_ATTN_REGFIN;  // see the kernel: gx = query units per (sequence, head), one per wave
+  const int gx = kWaveUnits ? (d.NP / 32 + QT - 1) / QT : (d.NP + QPB - 1) / QPB;
+  const size_t nwg = kWaveUnits ? (size_t)gx * d.S : (size_t)gx * 4 * d.S;
   static const bool trace_on = SSHIP_ATTN_TRACE_BUILD && getenv("SSHIP_ATTN_TRACE") != nullptr;
   if (trace_on) { (void)hipMalloc(&tbuf, nwg * 16 * 8); (void)hipMemsetAsync(tbuf, 0, nwg * 16 * 8, s); }
-  const int gx = (d.NP + QPB - 1) / QPB;
   static const bool xcd_off = getenv("SUPERSLAM_HIP_ATTN_XCD") && atoi(getenv("SUPERSLAM_HIP_ATTN_XCD")) == 0;  // A/B: plain id order
-  hipLaunchKernelGGL((k_lg_attention<QT, KS, V>), dim3(((size_t)gx * 4 * d.S + 7) / 8 * 8), dim3(256), smem, s, q, k, vt, lens, d.NP,
+  hipLaunchKernelGGL((k_lg_attention<QT, KS, V>), dim3((nwg + 7) / 8 * 8), dim3(256), smem, s, q, k, vt, lens, d.NP,
                      cross ? 1 : 0, ctx, tbuf, gx, xcd_off ? -d.S : d.S);
   if (trace_on) {
     std::vector<unsigned long long> h(nwg * 16);
