@@ -23,8 +23,10 @@ assert sp.initialize(), sp.last_error
 l, r = make_stereo_pair(H, W, 1234)
 imgs = torch.from_numpy(np.stack([l, r] * P)).cuda()
 imgs = torch.stack([torch.roll(imgs[i], i * 7, 0) for i in range(2 * P)])
+_lib.lib().sship_set_profiling(1)  # the handle keeps a copy of this call's pixels: the layers are re-launched on real data
 sp.extract_batch_device(imgs)
 torch.cuda.synchronize()
+_lib.lib().sship_set_profiling(0)
 names = ["c1a*", "conv1ab", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convPb", "cDa*", "cDb*", "nms", "topk", "desc"]
 out = []
 for lid, name in enumerate(names):

@@ -753,7 +753,9 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
     const Tensor* b = w ? find_tensor(sd, std::string(l.name) + ".bias", {l.cout}, err) : nullptr;
     if (!w || !b) return fail(SSHIP_ERR_IO, err);
     if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, l.ks, l.ct, *l.dst)) return rc;
-    if (l.ks == 3 && l.cin == 128 && std::string(l.name) != "convDa")   // convDa keeps the k order the sparse descriptor head shares
+    // second packing (64-row cout tiles over 32-channel chunks) for the kernels of conv_pp128.hip; conv1b runs fused with conv1a
+    // (conv_pp.hip), convDa keeps the k order the sparse descriptor head shares
+    if (l.ks == 3 && std::string(l.name) != "convDa" && std::string(l.name) != "conv1b")
       if (int rc = upload_conv_q(w->data.data(), l.cout, l.cin, *l.dst)) return rc;
     if (std::string(l.name) == "convDb")
       if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, 1, 32, sp->cDb32)) return rc;

@@ -555,11 +555,17 @@ hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int 
   if ((size_t)H * W * w.cin * 2 >= 0x7f000000ull) return hipErrorInvalidValue;  // staging offsets inside one image are 32-bit
   PpArgs a{};
   a.in = in; a.wpack = w.w; a.bias = w.bias; a.out = out; a.B = B; a.H = H; a.W = W; a.cout = w.cout;
+  // SUPERSLAM_HIP_CONV64=dma (A/B runs): the 16-row-tile LDS-DMA kernel of conv_pp128.hip with both 32-channel chunks' weights
+  // resident.  Measured at 128 images: conv2a 1 115 -> 1 170 us, conv2b 965 -> 954, conv3a 531 -> 565
+  // (profiles/r03_n_conv128_16row_tiles_lds_dma.txt) - with the whole weight set in LDS this file's kernel has no weight DMA to
+  // save and its two-stage register staging hides the HBM latency better than a DMA that must land within one half-step.
+  static const bool dma64 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV64"); return e && std::string(e) == "dma"; }();
+  if (w.cin == 64 && w.w_q && dma64 && sp_conv3x3_pp128_fits(B, H, W, 64)) return sp_conv3x3_pp128(w, in, out, B, H, W, pool, s);
   if (w.cin == 64 && w.ct == 64) return pool ? launch_pp<64, 64, true, false>(a, s) : launch_pp<64, 64, false, false>(a, s);
   // 128 input channels: the 64-row-tile kernel over 32-channel chunks (conv_pp128.hip) when the layer carries that packing;
   // SUPERSLAM_HIP_CONV128=ct32 keeps the 32-row-tile kernel of this file (A/B runs)
   static const bool ct32 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV128"); return e && std::string(e) == "ct32"; }();
-  if (w.cin == 128 && w.w_q && !ct32 && sp_conv3x3_pp128_fits(B, H, W)) return sp_conv3x3_pp128(w, in, out, B, H, W, pool, s);
+  if (w.cin == 128 && w.w_q && !ct32 && sp_conv3x3_pp128_fits(B, H, W, 128)) return sp_conv3x3_pp128(w, in, out, B, H, W, pool, s);
   if (w.cin == 128 && w.ct == 32) return pool ? launch_pp<128, 32, true, false>(a, s) : launch_pp<128, 32, false, false>(a, s);
   return hipErrorInvalidValue;
 }

@@ -65,7 +65,7 @@ hipError_t sp_conv3x3_strip(const ConvW& w, const _Float16* in, _Float16* out, i
 hipError_t sp_conv1ab_fused(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img,
                             _Float16* out, int B, int H, int W, hipStream_t s);
 hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s);
-bool sp_conv3x3_pp128_fits(int B, int H, int W);
+bool sp_conv3x3_pp128_fits(int B, int H, int W, int cin);
 hipError_t sp_conv3x3_pp128(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s);
 hipError_t sp_conv1ab_pp(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img, _Float16* out,
                          int B, int H, int W, hipStream_t s);
