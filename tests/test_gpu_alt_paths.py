@@ -165,14 +165,18 @@ def test_conv_kernels_agree_on_tile_corner_cases(weights_dir, tmp_path):
     walk, uneven tile split between the two wave groups).  fp16 activations, different fp32 summation orders: logits
     (O(25)) within 4e-2, unit-norm descriptor grid within 1e-2."""
     res = {}
-    for name, env in (("default", {}), ("strip", {"SUPERSLAM_HIP_CONV": "strip"}), ("ct32", {"SUPERSLAM_HIP_CONV128": "ct32"})):
+    # th8: the 8-row-tile register-staged kernel the 128-channel layers ran on before the 16-row LDS-DMA kernel; dma64: the
+    # LDS-DMA kernel also for the 64-channel layers (two resident chunks) - both opt-in A/B paths of conv_pp128.hip
+    variants = (("default", {}), ("strip", {"SUPERSLAM_HIP_CONV": "strip"}), ("ct32", {"SUPERSLAM_HIP_CONV128": "ct32"}),
+                ("th8", {"SUPERSLAM_HIP_CONV128": "th8"}), ("dma64", {"SUPERSLAM_HIP_CONV64": "dma"}))
+    for name, env in variants:
         out = str(tmp_path / ("dense_" + name + ".npz"))
         code = _DENSE_WORKER.format(root=ROOT, sp_path=weights_dir["sp_path"], shapes=_DENSE_SHAPES, out=out)
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[name] = np.load(out)
     for (h, w, _) in _DENSE_SHAPES:
-        for alt in ("strip", "ct32"):
+        for alt in ("strip", "ct32", "th8", "dma64"):
             dl = np.abs(res["default"]["l_%dx%d" % (h, w)] - res[alt]["l_%dx%d" % (h, w)]).max()
             dd = np.abs(res["default"]["d_%dx%d" % (h, w)] - res[alt]["d_%dx%d" % (h, w)]).max()
             print(f"{h}x{w} default vs {alt}: logits max|d| {dl:.3e}, descriptor grid max|d| {dd:.3e}")
