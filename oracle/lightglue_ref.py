@@ -1,10 +1,15 @@
 """CPU restatement of the LightGlue(features='superpoint') matcher (TEST INFRASTRUCTURE).
 
-PARITY UNPINNED.  The arithmetic lives in the third-party package
+PARITY: PINNED AGAINST AN INDEPENDENT PORT, UNPINNED AGAINST THE PACKAGE THE REFERENCE IMPORTS.
+The arithmetic lives in the third-party package
 ``lightglue @ git+https://github.com/cvg/LightGlue.git`` (no tag/commit pinned:
 /root/reference/utils/convert_lightglue_to_onnx.py:8), which is absent from /root/reference and
 from this image, and none of the reference's tests hold a known-answer vector for
-matches0/mscores0.  This file restates the published upstream ``lightglue/lightglue.py`` algorithm
+matches0/mscores0.  What the image does hold is transformers' port of the same model
+(transformers.models.lightglue, 5.15.0): oracle/pin_hf.py re-keys the seeded weights into it and
+tests/test_oracle_pins_hf.py asserts identical matches0, mscores0 and every layer's residual stream
+within 2e-6 (the port's fp32 rotary / softmax), and that ten mutations of this file break the
+comparison.  oracle/pin_oracles.py is the remaining check against the cvg package itself.  This file restates the published upstream ``lightglue/lightglue.py`` algorithm
  under the export-time overrides the reference applies:
   * in-graph normalize_keypoints patched to a no-op ......... convert_lightglue_to_onnx.py:61
   * flash = False, depth_confidence = width_confidence = -1 . :71-74  (all 9 layers, no pruning)
