@@ -120,8 +120,28 @@ def build_hf_lightglue(sd: dict):
     if unexpected or missing or bad:
         raise AssertionError(f"key layout mismatch: unexpected {unexpected[:6]}, missing {missing[:6]}, shapes {bad[:6]}")
     model.load_state_dict({k: v.to(own[k].dtype) for k, v in hf.items()}, strict=False)
+    if not hasattr(M, "_sship_orig_normalize_keypoints"):
+        M._sship_orig_normalize_keypoints = M.normalize_keypoints
     M.normalize_keypoints = lambda keypoints, height, width: keypoints  # convert_lightglue_to_onnx.py:61 - the wrapper normalises, not the graph
     return model.double(), torch
+
+
+def run_hf_lightglue_pixels(model, torch, kp0_px, d0, kp1_px, d1, height, width):
+    """The port with its OWN in-graph keypoint normalisation (the one the reference's exporter patches out and re-implements in
+    LightGlue.cc:241-251): pixel keypoints in, matches0 / mscores0 out.  Equal counts only."""
+    from transformers.models.lightglue import modeling_lightglue as M
+
+    patched = M.normalize_keypoints
+    M.normalize_keypoints = M._sship_orig_normalize_keypoints
+    try:
+        n = kp0_px.shape[0]
+        kp = torch.stack([kp0_px, kp1_px])[None].double()
+        ds = torch.stack([d0, d1])[None].double()
+        with torch.no_grad():
+            out = model._match_image_pair(kp, ds, height, width, mask=torch.ones((1, 2, n), dtype=torch.int64))
+        return out[0].reshape(1, 2, n)[0, 0], out[1].reshape(1, 2, n)[0, 0]
+    finally:
+        M.normalize_keypoints = patched
 
 
 def run_hf_lightglue(model, torch, k0, d0, k1, d1):

@@ -64,6 +64,35 @@ def test_a_broken_oracle_fails_the_pin(mutation):
     assert bad["matches_differ"] > 0 or max(bad["mscores_maxd"], bad["layers_maxd"]) > 100 * pin_hf.TOL, (mutation, bad)
 
 
+@needs_lg
+def test_wrapper_normalisation_plus_patched_graph_equals_the_unpatched_port():
+    """The reference patches the package's in-graph normalize_keypoints to a no-op (convert_lightglue_to_onnx.py:61) and normalises
+    in its C++ wrapper instead (LightGlue.cc:241-251, restated in oracle/hostpath_ref.c).  The port fed PIXEL keypoints with its own,
+    un-patched normalisation must give what the oracle gives on wrapper-normalised keypoints: same matches, mscores0 within 1e-5
+    (the wrapper normalises in fp32)."""
+    import numpy as np
+
+    from oracle import hostpath
+    from oracle import lightglue_ref as LR
+
+    sd = make_lightglue_weights(1)
+    model, _ = pin_hf.build_hf_lightglue(sd)
+    gen = torch.Generator().manual_seed(21)
+    n, w, h = 120, 1376, 376
+    px0 = torch.rand((n, 2), generator=gen) * torch.tensor([w - 1.0, h - 1.0])
+    px1 = (px0 + torch.tensor([-7.5, 0.25]) + 0.3 * torch.randn((n, 2), generator=gen)).clamp(min=0)
+    d0 = torch.nn.functional.normalize(torch.randn((n, 256), generator=gen, dtype=torch.float64), dim=-1)
+    d1 = torch.nn.functional.normalize(d0 + 0.05 * torch.randn((n, 256), generator=gen, dtype=torch.float64), dim=-1)
+    m_hf, s_hf = pin_hf.run_hf_lightglue_pixels(model, torch, px0, d0, px1, d1, h, w)
+    k0 = torch.from_numpy(hostpath.normalize_kpts(px0.numpy().astype(np.float32), w, h))
+    k1 = torch.from_numpy(hostpath.normalize_kpts(px1.numpy().astype(np.float32), w, h))
+    with torch.no_grad():
+        m_ref, s_ref = LR.match(sd, k0[None], d0[None], k1[None], d1[None])
+    assert int((m_hf >= 0).sum()) >= 60
+    assert torch.equal(m_hf.to(torch.int32), m_ref[0]), int((m_hf.to(torch.int32) != m_ref[0]).sum())
+    assert float((s_hf - s_ref[0].double()).abs().max()) < 1e-5
+
+
 @needs_resnet
 def test_eigenplaces_trunk_agrees_with_the_transformers_resnet18():
     """ResNet-18 trunk of oracle/eigenplaces_ref.py == transformers' ResNetModel (basic layers, 2-2-2-2) with the same weights,
