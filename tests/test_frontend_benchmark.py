@@ -177,6 +177,40 @@ def test_png_and_pgm_decoders_bit_exact(tmp_path):
     assert subprocess.run([_build_io_test(), str(bad)], capture_output=True, timeout=60).returncode == 1
 
 
+def test_png_decoder_reads_files_of_an_independent_encoder(tmp_path):
+    """The same decoder against PNGs written by Pillow (adaptive row filters, several zlib levels, `optimize`, a KITTI-sized
+    1241 x 376 frame, RGB, RGBA, 16-bit gray) - an encoder this repository's author did not write.  Modes the runner does not
+    support (palette, Adam7 interlace) must be refused with exit status 1, not decoded into garbage."""
+    PIL = pytest.importorskip("PIL.Image")
+    from oracle import hostpath as H
+    from superslam_amd.synth import make_frame
+
+    g = make_frame(376, 1241, 8, n_rects=40)
+    small = make_frame(61, 47, 9, n_rects=5)
+    rgb = np.stack([make_frame(61, 47, 10, n_rects=5), small, make_frame(61, 47, 11, n_rects=5)], -1)
+    cases = {}
+    for lvl, opt in ((1, False), (6, False), (9, True)):
+        name = f"kitti_l{lvl}.png"
+        PIL.fromarray(g, "L").save(tmp_path / name, compress_level=lvl, optimize=opt)
+        cases[name] = g
+    PIL.fromarray(rgb, "RGB").save(tmp_path / "rgb.png")
+    cases["rgb.png"] = H.bgr2gray_u8(rgb[..., ::-1])
+    rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 200, np.uint8)], -1)
+    PIL.fromarray(rgba, "RGBA").save(tmp_path / "rgba.png")
+    cases["rgba.png"] = H.bgr2gray_u8(rgb[..., ::-1])           # cv::imread(IMREAD_COLOR) drops alpha
+    PIL.fromarray(small.astype(np.uint16) * 257).save(tmp_path / "g16.png")  # uint16 -> mode I;16
+    cases["g16.png"] = small                                     # cv::imread without IMREAD_ANYDEPTH scales 16 -> 8 bit
+    for name, want in cases.items():
+        out = subprocess.run([_build_io_test(), str(tmp_path / name)], capture_output=True, timeout=60)
+        assert out.returncode == 0, (name, out.stderr)
+        hdr, _, body = out.stdout.partition(b"\n")
+        r, c = map(int, hdr.split())
+        np.testing.assert_array_equal(np.frombuffer(body, np.uint8).reshape(r, c), want, err_msg=name)
+    PIL.fromarray(small, "L").convert("P").save(tmp_path / "palette.png")
+    out = subprocess.run([_build_io_test(), str(tmp_path / "palette.png")], capture_output=True, timeout=60)
+    assert out.returncode == 1, out.stdout[:64]
+
+
 @pytest.mark.gpu
 def test_benchmark_runner_reads_a_kitti_style_png_sequence_through_the_upload_ring(weights_dir, tmp_path):
     from superslam_amd.synth import make_stereo_pair
