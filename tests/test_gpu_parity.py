@@ -340,6 +340,31 @@ def test_lightglue_vs_oracle_selfcheck_vectors(lg, weights_dir, golden_dir, tag)
     assert (np.diff(res.query_idx) > 0).all()
 
 
+@pytest.mark.parametrize("n", [64, 600])
+def test_lightglue_vs_the_transformers_port_directly(lg, weights_dir, n):
+    """The HIP matcher against transformers' port of cvg/LightGlue itself (not via oracle/lightglue_ref.py): the same seeded weights
+    re-keyed into the port, the same PIXEL keypoints - through sship's C ABI on one side, through the port's own in-graph
+    normalisation on the other - and the suite's usual bars (>= 99 % of matches0 identical, mscores0 within 2e-2, fp16 engine
+    against fp64 port).  n = 600 is the benchmarked problem size."""
+    from oracle import pin_hf
+    if not pin_hf.hf_lightglue_available():
+        pytest.skip("transformers without the LightGlue port")
+    model, _ = pin_hf.build_hf_lightglue(weights_dir["lg"])
+    gen = torch.Generator().manual_seed(100 + n)
+    W, Hh = 1376, 376
+    px0 = torch.rand((n, 2), generator=gen) * torch.tensor([W - 1.0, Hh - 1.0])
+    px1 = (px0 + torch.tensor([-9.0, 0.5]) + 0.4 * torch.randn((n, 2), generator=gen)).clamp(min=0)
+    d0 = torch.nn.functional.normalize(torch.randn((n, 256), generator=gen), dim=-1)
+    d1 = torch.nn.functional.normalize(d0 + 0.06 * torch.randn((n, 256), generator=gen), dim=-1)
+    d0h, d1h = d0.half().float(), d1.half().float()            # what the engine is fed: fp16 descriptors
+    res = lg.match(px0.numpy(), d0h.numpy(), px1.numpy(), d1h.numpy())
+    m_hf, s_hf = pin_hf.run_hf_lightglue_pixels(model, torch, px0.double(), d0h.double(), px1.double(), d1h.double(), Hh, W)
+    c = _lgcmp.compare(res.matches0, res.mscores0, m_hf.numpy().astype(np.int32), s_hf.numpy().astype(np.float32))
+    print(f"LG vs transformers port, n={n}: {c}")
+    assert int((m_hf >= 0).sum()) >= n // 2
+    _lgcmp.check(c)
+
+
 def test_lightglue_on_superpoint_features(sp, lg, weights_dir):
     """Full-size pair: device-descriptor match on real pool slots vs the oracle on the same inputs."""
     from superslam_amd.synth import make_stereo_pair
