@@ -22,7 +22,7 @@ __device__ __forceinline__ f16v mfma(h8 a, h8 b, f16v c) { return __builtin_amdg
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 template <int MODE>
-__global__ __launch_bounds__((MODE >= 6 ? 512 : 1024)) void k(unsigned long long* out, float* sink, int iters, const _Float16* kv, int share) {
+__global__ __launch_bounds__((MODE >= 6 && MODE <= 8 ? 512 : 1024)) void k(unsigned long long* out, float* sink, int iters, const _Float16* kv, int share) {
   const int lane = threadIdx.x & 63;
   h8 a, b, a2, b2;
   for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.01f * (lane + e)); b[e] = (_Float16)(0.02f * (lane - e)); a2[e] = (_Float16)(0.03f * (lane + 2 * e)); b2[e] = (_Float16)(0.015f * (lane - 3 * e)); }
@@ -62,7 +62,7 @@ __global__ __launch_bounds__((MODE >= 6 ? 512 : 1024)) void k(unsigned long long
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (MODE >= 6) {
+    if (MODE >= 6 && MODE <= 8) {
       // mode 6: mode 5 + the kernel's K / V^T fragment traffic: 8 x 1 KiB wave loads per iteration from an L2-resident 156 KB
       //         region per (block, wave pair), requested one iteration ahead into a second register set (two sets alternate);
       // mode 7: + lane^32 exchange of the tile maximum (v_permlane32_swap) and the `__any(max > r + 8)` test with the rescale
@@ -131,6 +131,27 @@ __global__ __launch_bounds__((MODE >= 6 ? 512 : 1024)) void k(unsigned long long
       __builtin_amdgcn_sched_barrier(0);
       tile(fB, 2 * it + 1);
     }
+    if (MODE == 9 || MODE == 10) {
+      // Winograd F(2x2, 3x3)-shaped mix per 8 MFMAs (one group of four positions x two M-tiles, one 16-channel k-step):
+      //   input transform of the lane's tile column: 8 vector adds on 4 packed-fp16 registers = 32 v_pk_add_f16,
+      //   mode 10 also the output transform of one finished position group per FOUR such k-steps: 7 fp32 adds per MFMA on average
+      //   (224 v_add_f32 per 32 MFMAs), i.e. 56 per iteration here.
+      // (instruction counts pinned with inline asm: the compiler folded a third of a C++ version away)
+      unsigned* ua = reinterpret_cast<unsigned*>(&fA[0]);
+      unsigned* ub = reinterpret_cast<unsigned*>(&fB[0]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if ((r & 3) == 0) c0 = mfma(fA[r & 7], b, c0); else if ((r & 3) == 1) c1 = mfma(fA[(r + 1) & 7], b2, c1); else if ((r & 3) == 2) c2 = mfma(fB[r & 7], b, c2); else c3 = mfma(fB[(r + 1) & 7], b2, c3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(ua[(4 * r + i) & 31]) : "v"(ub[(4 * r + i + 5) & 31]));
+        if (MODE == 10) {
+#pragma unroll
+          for (int i = 0; i < 7; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[(7 * r + i) & 15]) : "v"(x[(7 * r + i + 3) & 15]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     if (MODE == 4 || MODE == 5) {
       const f16v z = {0};
       f16v s[2];
@@ -174,8 +195,8 @@ __global__ __launch_bounds__((MODE >= 6 ? 512 : 1024)) void k(unsigned long long
 static _Float16* kvbuf = nullptr;
 template <int MODE>
 static void run(const char* name, unsigned long long* d, float* sink, int share = 5) {
-  const int iters = MODE >= 6 ? 1000 : 2000, nblk = 256;  // modes >= 6 run two key tiles per loop iteration: figures are per TWO tiles
-  for (int wps = 1; wps <= (MODE >= 6 ? 2 : 4); ++wps) {  // waves per SIMD (modes >= 6 need ~200 VGPRs: two at most)
+  const int iters = MODE >= 6 && MODE <= 8 ? 1000 : 2000, nblk = 256;  // modes >= 6 run two key tiles per loop iteration: figures are per TWO tiles
+  for (int wps = 1; wps <= (MODE >= 6 && MODE <= 8 ? 2 : 4); ++wps) {  // waves per SIMD (modes >= 6 need ~200 VGPRs: two at most)
     hipMemset(d, 0, nblk * 16 * 8);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -208,6 +229,8 @@ int main() {
   run<7>("7 = 6 + vote / rescale (x2)", d, sink);
   run<8>("8 = 7 + ragged / first (x2)", d, sink);
   run<8>("8, no sharing across WGs", d, sink, 1);
+  run<9>("9 winograd-like: 8 mfma | 32 v_pk_add_f16", d, sink);
+  run<10>("10 = 9 + 56 v_add_f32 (output transform)", d, sink);
   {  // the same loops on random operands: what the DVFS power limit takes
     std::vector<_Float16> hkv(kvn);
     unsigned h = 1;
@@ -216,6 +239,8 @@ int main() {
     run<0>("0 mfma x16, random", d, sink, -5);
     run<5>("5, random operands", d, sink, -5);
     run<8>("8, random operands", d, sink, -5);
+    run<9>("9, random operands", d, sink, -5);
+    run<10>("10, random operands", d, sink, -5);
   }
   return 0;
 }
