@@ -2,7 +2,7 @@
 """bench.py - stereo pairs/sec of the front-end hot path (SuperPoint x2 + select + gather + LightGlue)
 on 1376x376 KITTI-shaped synthetic frames (BASELINE.json metric / configs[1]).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W      (N > 1 without a launcher: re-executes itself as the next line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step is ONE pass of the hot path over one batch of synthetic input: `--chunks` x `--pairs` stereo pairs that are
@@ -202,6 +202,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="warm-up + timed steps only (profiling passes)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: re-execute as N ranks under torch.distributed.run (does not return then)
+    from superslam_amd.shard import relaunch_under_launcher_if_needed
+    relaunch_under_launcher_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     import numpy as np
     import torch

@@ -162,8 +162,17 @@ int sship_sp_extract_stereo_ring(sship_sp* sp, int slot, sship_features* out_lef
  * pinned buffers) on the extractor's stream and returns at once; the later sship_sp_extract_stereo_ring(slot) only waits for
  * that work's completion event and hands the results out.  Called right after frame t's extraction has returned - before frame
  * t's LightGlue match - it lets frame t+1's SuperPoint kernels share the GPU with frame t's matcher (the matcher's launches
- * cover a fraction of the CUs at one pair).  Same thread as every other call on this handle; at most one submission per slot;
- * other extractor calls in between are ordered by the handle's stream and do not disturb a pending submission. */
+ * cover a fraction of the CUs at one pair).  Same thread as every other call on this handle; at most one submission per slot.
+ * Constraints while a submission is pending (submitted, not yet collected):
+ *   - sship_sp_ring_upload(slot) on that slot returns SSHIP_ERR_INVALID: the queued network still reads the slot's device
+ *     frame (collect first, then refill);
+ *   - the synchronous extractor calls (sship_sp_extract*, sship_sp_extract_stereo_ring of another slot) run on the handle's
+ *     own stream and are ordered behind the submission;
+ *   - sship_sp_extract_batch_device / sship_frontend_batch_device on a caller-supplied NON-BLOCKING stream share the handle's
+ *     activations with the submission and are NOT ordered with it: do not overlap them with a pending submission;
+ *   - sship_sp_destroy with a submission pending waits for it and returns its pool slots.
+ * Stage timings: sship_sp_ring_submit restarts the calling thread's stage marks, so under pipelining
+ * sship_get_stage_timings mixes frame t+1's extraction stages with frame t's match stages - profile un-pipelined. */
 int sship_sp_ring_submit(sship_sp* sp, int slot);
 /* SuperPoint::infer host path (src/SuperPoint.cc:322-348,427-528): keypoints + CV_32F [n,256] descriptors
  * on the host.  kp_xys [3*max_kp], desc_f32 [max_kp*256]. */
@@ -268,6 +277,29 @@ int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs_
                                 void* desc_out_dev, float* kp_out_dev, int* n_out_dev,
                                 int32_t* matches0_dev, float* mscores0_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange (BASELINE configs 3 and 5).  No reference counterpart: the reference is single-GPU.
+ * Frames / pairs / cameras are sharded over one process per GPU with replicated weights and NO data-path collective; the
+ * one exchange step is a fixed-stride all-gather of every rank's padded results into the image of the shared
+ * DescriptorPool (include/DescriptorPool.h:13-91: [count, 256] fp16 rows per frame) on every rank.  RCCL (xGMI) is bound
+ * at run time; without it these calls return SSHIP_ERR_NO_DEVICE and the rest of the library is unaffected.
+ *   rank 0:      sship_comm_unique_id(id)  ->  hand the 128 bytes to the other ranks out of band (file, MPI, torch store, ...)
+ *   every rank:  sship_init(device); sship_comm_create(id, rank, world, &comm)       (collective: all ranks must call)
+ *   per batch:   sship_gather_features_rccl(comm, desc, kp, n, units, max_kp, desc_all, kp_all, n_all, stream)
+ * Buffers are device memory: local desc [units, max_kp, 256] f16, kp [units, max_kp, 3] f32, n [units] i32; the *_all buffers
+ * hold world x units units in rank order (rank r's block at r * units); ranks with fewer real units pad with n = 0.
+ * The three all-gathers go out as ONE grouped RCCL step on `stream` (asynchronous; NULL = the default stream).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sship_comm sship_comm;
+int sship_comm_unique_id(void* id_out_128);
+int sship_comm_create(const void* id_128, int rank, int world, sship_comm** out);
+void sship_comm_destroy(sship_comm* comm);
+int sship_comm_rank(const sship_comm* comm);
+int sship_comm_world(const sship_comm* comm);
+int sship_gather_features_rccl(sship_comm* comm, const void* desc_local_dev, const float* kp_local_dev, const int* n_local_dev,
+                               int units_per_rank, int max_keypoints, void* desc_all_dev, float* kp_all_dev, int* n_all_dev,
+                               void* stream);
+
 /* Per-stage device timings (ms) of the calling thread's last call sequence made with profiling enabled
  * (sship_set_profiling(1) inserts hipEvents; off by default; level 2 adds one event per SuperPoint layer launch - labels
  * "<scope>:<stage>/<layer>", e.g. "sp_gpu_infer:encoder/conv1a+conv1b+pool" - the IN-SITU launch durations bench.py's roofline
@@ -275,7 +307,8 @@ int sship_frontend_batch_device(sship_sp* sp, sship_lg* lg, const uint8_t* imgs_
  * reference's own SUPERSLAM_PROFILE label the stage belongs to - sp_gpu_infer (src/SuperPoint.cc:639),
  * sp_extract_stereo (:904), fe_lg_stereo_match (src/StereoFrontEnd.cc:32) - and <stage> this library's finer split
  * (encoder, heads, select, gather, posenc_qkv0, layers_x9, assign_filter); summing a scope's stages gives the
- * reference's figure.  Timers are per thread.  Returns the number of stages. */
+ * reference's figure.  At level 2 the SuperPoint stages are reported ONLY as their per-launch entries ("sp_gpu_infer:encoder/conv2a",
+ * ...): no entry carries the bare "<scope>:<stage>" label, a stage's time is the sum over its "<scope>:<stage>/..." entries.  Timers are per thread.  Returns the number of stages. */
 void sship_set_profiling(int level);
 int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
 

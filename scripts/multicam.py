@@ -24,7 +24,10 @@ def main():
     ap.add_argument("--w", type=int, default=1280)
     ap.add_argument("--max-kp", type=int, default=1024)
     ap.add_argument("--ticks", type=int, default=20)
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without a launcher: re-executes under torch.distributed.run with N ranks")
     args = ap.parse_args()
+    from superslam_amd.shard import relaunch_under_launcher_if_needed
+    relaunch_under_launcher_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     import numpy as np
     import torch

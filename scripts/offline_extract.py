@@ -27,9 +27,12 @@ def main():
     ap.add_argument("--w", type=int, default=752)
     ap.add_argument("--max-kp", type=int, default=600)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without a launcher: re-executes under torch.distributed.run with N ranks")
     ap.add_argument("--dump", default=None, help="rank 0 writes the gathered (desc, kp, n) to this .npz (the multi-rank rehearsal test "
                                                   "compares it bit-for-bit with a single-process run)")
     args = ap.parse_args()
+    from superslam_amd.shard import relaunch_under_launcher_if_needed
+    relaunch_under_launcher_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     import numpy as np
     import torch

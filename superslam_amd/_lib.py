@@ -90,6 +90,12 @@ _SIGS = {
     "sship_set_profiling": (None, [ip]),
     "sship_get_stage_timings": (ip, [C.POINTER(C.c_char_p), C.POINTER(fp), ip]),
     "sship_set_log_callback": (None, [vp]),
+    "sship_comm_unique_id": (ip, [vp]),
+    "sship_comm_create": (ip, [vp, ip, ip, C.POINTER(vp)]),
+    "sship_comm_destroy": (None, [vp]),
+    "sship_comm_rank": (ip, [vp]),
+    "sship_comm_world": (ip, [vp]),
+    "sship_gather_features_rccl": (ip, [vp, vp, vp, vp, ip, ip, vp, vp, vp, vp]),
 }
 
 

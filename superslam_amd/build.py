@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsuperslam_hip.so")
-SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "conv_pp128.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip"]
+SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "conv_pp128.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 # per-file flags.  -fno-honor-nans: under IEEE NaN semantics every fmaxf() operand that comes out of an MFMA is
@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     return LIB
 
 
@@ -79,7 +79,7 @@ def build_variant(name: str, extra_flags) -> str:
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(one, SOURCES))
     out = os.path.join(vdir, name + ".so")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"], check=True)
     return out
 
 

@@ -669,8 +669,9 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
   // conv1a is evaluated inside conv1b's tile staging (conv_pp.hip): the 64-channel full-resolution activation
   // never exists in HBM.
-  // level-2 profiling: one mark per launch ("sp_gpu_infer:encoder/<layer>"); the LAST launch of a group carries the group's
-  // level-1 label, so summing a scope's stages gives the same figure at either level
+  // level-2 profiling: one mark per launch, labelled "<level-1 label>/<layer>" ("sp_gpu_infer:encoder/conv2a", ...,
+  // "sp_gpu_infer:encoder/conv4b", "sp_gpu_infer:heads/convPb", "sp_extract_stereo:select/topk").  At level 2 NO entry
+  // carries the bare level-1 label: a stage's level-1 time is the SUM over its "<label>/..." entries (what bench.py does)
   SSHIP_HIP_CHECK(conv1ab(sp, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
   g_timer.mark_fine("sp_gpu_infer:encoder/conv1a+conv1b+pool", s);
   SSHIP_HIP_CHECK(conv3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));
@@ -821,8 +822,9 @@ extern "C" void sship_sp_destroy(sship_sp* sp) {
   if (sp->b1a) (void)hipFree(sp->b1a);
   if (sp->w1a_frag) (void)hipFree(sp->w1a_frag);
   if (sp->w1a_fragb) (void)hipFree(sp->w1a_fragb);
+  ring_free(sp);  // BEFORE the pool: an uncollected sship_sp_ring_submit hands its slots back to sp->pool
   if (sp->pool) sship_pool_destroy(sp->pool);
-  ring_free(sp);
+  sp->pool = nullptr;
   if (sp->stream) (void)hipStreamDestroy(sp->stream);
   delete sp;
 }
@@ -1108,18 +1110,26 @@ extern "C" int sship_sp_ring_upload(sship_sp* sp, int slot) {
   bind_thread();
   if (!sp || slot < 0 || slot >= sp->ring.depth) return fail(SSHIP_ERR_INVALID, "sp_ring_upload: bad slot");
   auto& r = sp->ring;
+  // a submitted, uncollected extraction may still be reading r.dev[slot] on sp->stream (directly for 1 channel, through
+  // bgr2gray for 3): re-uploading under it would race silently.  Collect first.
+  if (r.pending[slot].active)
+    return fail(SSHIP_ERR_INVALID, "sp_ring_upload: this slot has a submitted extraction that was not collected (sship_sp_extract_stereo_ring) yet");
   SSHIP_HIP_CHECK(hipMemcpyAsync(r.dev[slot], r.host[slot], 2 * r.img_bytes, hipMemcpyHostToDevice, r.copy_stream));
   SSHIP_HIP_CHECK(hipEventRecord(r.uploaded[slot], r.copy_stream));
   return SSHIP_OK;
 }
-static const uint8_t* ring_gray(sship_sp* sp, int slot) {  // the slot's pair as grayscale on the device, ordered with sp->stream
+// the slot's pair as grayscale on the device, ordered with sp->stream; a failed wait / launch is an error, not a partly uploaded frame
+static int ring_gray(sship_sp* sp, int slot, const uint8_t** gray) {
   auto& r = sp->ring;
-  (void)hipStreamWaitEvent(sp->stream, r.uploaded[slot], 0);
+  SSHIP_HIP_CHECK(hipStreamWaitEvent(sp->stream, r.uploaded[slot], 0));
   if (r.ch == 3) {
     launch_bgr2gray(static_cast<const uint8_t*>(r.dev[slot]), 2 * r.h * r.w, sp->img.as<uint8_t>(), sp->stream);
-    return sp->img.as<uint8_t>();
+    SSHIP_HIP_CHECK(hipGetLastError());
+    *gray = sp->img.as<uint8_t>();
+    return SSHIP_OK;
   }
-  return static_cast<const uint8_t*>(r.dev[slot]);
+  *gray = static_cast<const uint8_t*>(r.dev[slot]);
+  return SSHIP_OK;
 }
 extern "C" int sship_sp_ring_submit(sship_sp* sp, int slot) {
   bind_thread();
@@ -1128,7 +1138,8 @@ extern "C" int sship_sp_ring_submit(sship_sp* sp, int slot) {
   auto& pd = r.pending[slot];
   if (pd.active) return fail(SSHIP_ERR_INVALID, "sp_ring_submit: this slot already has a submitted extraction (collect it with sship_sp_extract_stereo_ring)");
   if (int rc = sp_ensure(sp, 2, r.h, r.w)) return rc;
-  const uint8_t* gray = ring_gray(sp, slot);
+  const uint8_t* gray = nullptr;
+  if (int rc = ring_gray(sp, slot, &gray)) return rc;
   if (int rc = sp_extract_enqueue(sp, gray, 2, r.h, r.w, pd.slots, &pd.rc_pool, static_cast<float*>(pd.h_kp), static_cast<int*>(pd.h_n))) return rc;
   SSHIP_HIP_CHECK(hipEventRecord(pd.done, sp->stream));
   pd.active = true;
@@ -1150,7 +1161,9 @@ extern "C" int sship_sp_extract_stereo_ring(sship_sp* sp, int slot, sship_featur
     return sp_extract_finish(sp, 2, pd.slots, pd.rc_pool, static_cast<const float*>(pd.h_kp), static_cast<const int*>(pd.h_n), outs);
   }
   if (int rc = sp_ensure(sp, 2, r.h, r.w)) return rc;
-  return sp_extract_device(sp, ring_gray(sp, slot), 2, r.h, r.w, outs);
+  const uint8_t* gray = nullptr;
+  if (int rc = ring_gray(sp, slot, &gray)) return rc;
+  return sp_extract_device(sp, gray, 2, r.h, r.w, outs);
 }
 extern "C" int sship_desc_to_host(const void* desc_dev, int count, int dim, float* out) {
   bind_thread();

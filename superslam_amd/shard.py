@@ -49,6 +49,36 @@ def dist_env():
     return rank, dev, world, "RANK" in os.environ, os.environ.get("SUPERSLAM_DIST_BACKEND", "nccl")
 
 
+def launcher_command(script: str, script_args: List[str], nproc: int, port: int | None = None) -> List[str]:
+    """The command line that re-runs `script` as one process per GPU of ONE node: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P script args...` (the form the driver itself uses for N > 1; 127.0.0.1
+    because a container hostname may not resolve).  `port`: a free TCP port is picked when None."""
+    import socket
+    import sys
+
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script, *script_args]
+
+
+def relaunch_under_launcher_if_needed(gpus: int, script: str, argv: List[str]) -> None:
+    """`python script.py --gpus N` with N > 1 and no launcher around it (RANK unset): replace this process by the launcher command
+    above, so the plain form the driver uses for N = 1 also works for N = 8 (VERDICT r03 "do this" 3).  Returns when nothing has to
+    be done (N <= 1, or already one of the launcher's ranks); otherwise does not return."""
+    import os
+
+    if gpus <= 1 or "RANK" in os.environ:
+        return
+    cmd = launcher_command(script, argv, gpus)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    os.execvpe(cmd[0], cmd, env)
+
+
 def init_process_group(backend: str, device_index: int):
     import os
 
@@ -73,39 +103,118 @@ def all_reduce_max_seconds(dt: float) -> float:
     return float(t.item())
 
 
+def _pack_units(desc, kp, n, per: int):
+    """(desc [u,K,256] f16, kp [u,K,3] f32, n [u] i32) -> ONE byte tensor [per, unit_bytes] (zero-padded to `per` units): a unit's
+    record is its descriptor rows, its keypoint rows and its count back to back, padded to 16 bytes."""
+    import torch
+
+    u, K = desc.shape[0], desc.shape[1]
+    db, kb = K * desc.shape[2] * desc.element_size(), K * kp.shape[2] * kp.element_size()
+    unit = (db + kb + 4 + 15) // 16 * 16
+    buf = torch.zeros((per, unit), dtype=torch.uint8, device=desc.device)
+    if u:
+        buf[:u, :db] = desc.contiguous().view(torch.uint8).reshape(u, db)
+        buf[:u, db:db + kb] = kp.contiguous().view(torch.uint8).reshape(u, kb)
+        buf[:u, db + kb:db + kb + 4] = n.contiguous().view(torch.uint8).reshape(u, 4)
+    return buf, db, kb
+
+
+def _unpack_units(buf, db: int, kb: int, K: int, desc_dtype, kp_dtype, n_dtype, dim: int = 256):
+    u = buf.shape[0]
+    desc = buf[:, :db].contiguous().view(desc_dtype).reshape(u, K, dim)
+    kp = buf[:, db:db + kb].contiguous().view(kp_dtype).reshape(u, K, -1)
+    n = buf[:, db + kb:db + kb + 4].contiguous().view(n_dtype).reshape(u)
+    return desc, kp, n
+
+
 def all_gather_features(desc, kp, n, total_units: int, group=None):
-    """Gather per-rank padded results into global tensors ordered by unit id (block sharding).
+    """Gather per-rank padded results into global tensors ordered by unit id (block sharding): the ONE exchange step of SURVEY 8(e).
 
     desc [u_local, K, 256], kp [u_local, K, 3], n [u_local]; ranks may own different unit counts (the tail
     ranks own one less), so each rank pads to ceil(total/world) units and the pad rows are dropped after the
-    collective - a fixed-stride all-gather instead of an all-gather-v.
+    collective - a fixed-stride all-gather instead of an all-gather-v.  The three tensors travel as ONE collective: every unit
+    is packed into a fixed-size byte record (round 3 issued three all-gathers per exchange).  The C-ABI twin for C++ hosts is
+    sship_gather_features_rccl (include/sship.h; one grouped RCCL step, no packing copy).
     """
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     per = (total_units + world - 1) // world
-    outs = []
     via_host = dist.get_backend(group) != "nccl" and desc.is_cuda   # gloo: device tensors are staged through the host
     home = desc.device
-    for t in (desc, kp, n):
-        if via_host:
-            t = t.cpu()
-        pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[: t.shape[0]] = t
-        full = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        try:
-            dist.all_gather_into_tensor(full, pad, group=group)
-        except (RuntimeError, NotImplementedError):
-            parts = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(parts, pad, group=group)
-            full = torch.cat(parts, 0)
-        keep = []
-        for r in range(world):
-            a, b = shard_block(total_units, r, world)
-            keep.append(full[r * per: r * per + (b - a)])
-        outs.append(torch.cat(keep, 0).to(home) if via_host else torch.cat(keep, 0))
-    return tuple(outs)
+    K = desc.shape[1]
+    buf, db, kb = _pack_units(desc, kp, n, per)
+    if via_host:
+        buf = buf.cpu()
+    full = torch.empty((world * per, buf.shape[1]), dtype=torch.uint8, device=buf.device)
+    try:
+        dist.all_gather_into_tensor(full, buf, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        full = torch.cat(parts, 0)
+    keep = []
+    for r in range(world):
+        a, b = shard_block(total_units, r, world)
+        keep.append(full[r * per: r * per + (b - a)])
+    full = torch.cat(keep, 0)
+    if via_host:
+        full = full.to(home)
+    return _unpack_units(full, db, kb, K, desc.dtype, kp.dtype, n.dtype, desc.shape[2])
+
+
+class RcclComm:
+    """The C ABI's communicator (sship_comm_*, include/sship.h) from Python: what a C++ host of SuperSLAM would hold.  The 128-byte
+    id is created on rank 0 and handed to the other ranks by the caller (here: through torch.distributed's store when a process
+    group exists; world size 1 needs no exchange)."""
+
+    def __init__(self, rank: int = 0, world: int = 1, id_bytes: bytes | None = None):
+        import ctypes as C
+
+        from . import _lib
+
+        L = _lib.lib()
+        if id_bytes is None:
+            if world > 1:
+                import torch.distributed as dist
+
+                box = [None]
+                if rank == 0:
+                    b = C.create_string_buffer(128)
+                    _lib.check(L.sship_comm_unique_id(b))
+                    box[0] = b.raw
+                dist.broadcast_object_list(box, src=0)
+                id_bytes = box[0]
+            else:
+                b = C.create_string_buffer(128)
+                _lib.check(L.sship_comm_unique_id(b))
+                id_bytes = b.raw
+        h = C.c_void_p()
+        _lib.check(L.sship_comm_create(id_bytes, rank, world, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    def gather_features(self, desc, kp, n, stream=None):
+        """desc [u,K,256] f16, kp [u,K,3] f32, n [u] i32 (device, same u on every rank) -> (world*u, ...) tensors in rank order."""
+        import torch
+
+        from . import _lib
+
+        u, K = desc.shape[0], desc.shape[1]
+        da = torch.empty((self.world * u, K, 256), dtype=torch.float16, device=desc.device)
+        ka = torch.empty((self.world * u, K, 3), dtype=torch.float32, device=desc.device)
+        na = torch.empty((self.world * u,), dtype=torch.int32, device=desc.device)
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().sship_gather_features_rccl(self._h, desc.data_ptr(), kp.data_ptr(), n.data_ptr(), u, K, da.data_ptr(),
+                                                         ka.data_ptr(), na.data_ptr(), st))
+        return da, ka, na
+
+    def close(self):
+        if self._h:
+            from . import _lib
+
+            _lib.lib().sship_comm_destroy(self._h)
+            self._h = None
 
 
 class HostDescriptorPool:

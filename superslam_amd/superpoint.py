@@ -143,13 +143,19 @@ class SuperPoint:
         rc = _lib.lib().sship_sp_ring_create(self._h, depth, h, w, channels)
         if rc != _lib.OK:
             self.last_error = (_lib.lib().sship_last_error() or b"").decode()
+            self._ring = None   # a failed create leaves no ring: ring_host must not dereference the NULL it would get
+            return False
         self._ring = (depth, h, w, channels)
-        return rc == _lib.OK
+        return True
 
     def ring_host(self, slot: int, image: int) -> np.ndarray:
         """The slot's pinned host image (0 = left, 1 = right) as a writable numpy view [h, w(, 3)]."""
+        if getattr(self, "_ring", None) is None:
+            raise RuntimeError("ring_host: no upload ring (ring_create was not called or failed)")
         _, h, w, ch = self._ring
         ptr = _lib.lib().sship_sp_ring_host(self._h, slot, image)
+        if not ptr:
+            raise IndexError(f"ring_host: no such slot / image ({slot}, {image})")
         buf = (C.c_uint8 * (h * w * ch)).from_address(ptr)
         a = np.frombuffer(buf, np.uint8)
         return a.reshape(h, w) if ch == 1 else a.reshape(h, w, ch)
@@ -168,7 +174,13 @@ class SuperPoint:
         fr = _lib.Features(kr.ctypes.data_as(C.POINTER(C.c_float)), 0, None, -1)
         rc = _lib.lib().sship_sp_extract_stereo_ring(self._h, slot, C.byref(fl), C.byref(fr))
         if rc != _lib.OK:
+            # the ring is this library's own API (no reference override whose "never throws" contract would apply):
+            # a failed collection (pool exhausted, device error) raises instead of handing out half-filled features
             self.last_error = (_lib.lib().sship_last_error() or b"").decode()
+            for f in (fl, fr):
+                if f.slot >= 0:
+                    _lib.lib().sship_pool_release(_lib.lib().sship_sp_pool(self._h), f.slot)
+            raise RuntimeError("extract_stereo_ring: " + self.last_error)
         return self._wrap(fl, kl), self._wrap(fr, kr)
 
     # ---- device-resident batch path (throughput) -----------------------------------------------

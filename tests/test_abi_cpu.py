@@ -69,3 +69,39 @@ def test_pure_host_helpers_work_without_gpu():
     k = _lib.lib().sship_filter_matches(m0.ctypes.data, ms.ctypes.data, 6, q.ctypes.data, t.ctypes.data, d.ctypes.data)
     assert k == 4 and q[:4].tolist() == [0, 2, 4, 5] and t[:4].tolist() == [3, 0, 7, 2]
     np.testing.assert_allclose(d[:4], [0.1, 0.75, 0.0, 0.875], atol=1e-7)
+
+
+def test_rccl_exchange_entry_points_validate_their_arguments_and_need_no_rccl_at_load_time():
+    """The multi-GPU exchange (sship_comm_* / sship_gather_features_rccl) binds RCCL at run time: the library has no DT_NEEDED on
+    librccl (single-GPU users need no RCCL), and bad arguments are refused before anything touches RCCL or a device."""
+    import ctypes as C
+
+    from superslam_amd import _lib
+
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.sship_comm_create(None, 0, 1, C.byref(h)) == _lib.ERR_INVALID
+    assert lib.sship_comm_create(b"\0" * 128, 3, 2, C.byref(h)) == _lib.ERR_INVALID          # rank outside the world
+    assert lib.sship_comm_unique_id(None) == _lib.ERR_INVALID
+    assert lib.sship_gather_features_rccl(None, None, None, None, 4, 600, None, None, None, None) == _lib.ERR_INVALID
+    assert b"communicator" in lib.sship_last_error()
+    assert lib.sship_comm_rank(None) == -1 and lib.sship_comm_world(None) == 0
+    lib.sship_comm_destroy(None)
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower() and "torch" not in needed.lower(), needed
+
+
+def test_single_collective_record_packing_round_trips():
+    """all_gather_features sends ONE byte record per unit (descriptor rows | keypoint rows | count, padded to 16 B)."""
+    import torch
+
+    from superslam_amd.shard import _pack_units, _unpack_units
+
+    g = torch.Generator().manual_seed(3)
+    desc = torch.randn((3, 7, 256), generator=g).half(); kp = torch.rand((3, 7, 3), generator=g)
+    n = torch.tensor([7, 0, 4], dtype=torch.int32)
+    buf, db, kb = _pack_units(desc, kp, n, per=5)
+    assert buf.shape == (5, (7 * 512 + 7 * 12 + 4 + 15) // 16 * 16) and buf.dtype == torch.uint8
+    d2, k2, n2 = _unpack_units(buf, db, kb, 7, desc.dtype, kp.dtype, n.dtype)
+    assert torch.equal(d2[:3], desc) and torch.equal(k2[:3], kp) and torch.equal(n2[:3], n)
+    assert int(n2[3:].abs().sum()) == 0 and float(d2[3:].abs().sum()) == 0.0

@@ -250,3 +250,45 @@ def test_ring_submit_is_bit_identical_to_extract_stereo_and_survives_interleavin
     assert sp.ring_create(2, h, w, 1)                    # re-creating the ring drops it and returns the slots
     assert sp.pool_in_use() == 0
     sp.close(); lg.close()
+
+
+def test_closing_a_handle_with_an_uncollected_submission_and_reupload_of_a_pending_slot(weights_dir):
+    """(i) sship_sp_destroy with a submission pending used to release the submission's pool slots into a pool that had
+    already been destroyed (a mutex lock + vector push in freed memory): the ring now goes first.  A surviving descriptor handle
+    keeps the pool's bookkeeping alive across the close, so its late release must stay harmless.  (ii) re-uploading a slot whose
+    submitted extraction has not been collected would race with the queued network: refused with an error."""
+    import gc
+
+    from superslam_amd import SuperPoint, _lib
+    from superslam_amd.synth import make_stereo_pair
+
+    h, w = 240, 376
+    for ch in (1, 3):
+        sp = SuperPoint(weights_dir["sp_path"], 300, 0.005, 4, max_batch=2)
+        assert sp.initialize()
+        assert sp.ring_create(2, h, w, ch), sp.last_error
+        l, r = make_stereo_pair(h, w, 77)
+        for s in range(2):
+            for i, im in enumerate((l, r)):
+                sp.ring_host(s, i)[:] = im if ch == 1 else np.repeat(im[:, :, None], 3, axis=2)
+            sp.ring_upload(s)
+        sp.ring_submit(0)
+        with pytest.raises(_lib.SshipError):
+            sp.ring_upload(0)                            # pending: the queued network still reads the slot's device frame
+        fl, fr = sp.extract_stereo_ring(0)               # collect ...
+        sp.ring_upload(0)                                # ... then the slot can be refilled
+        sp.ring_submit(0); sp.ring_submit(1)
+        assert sp.pool_in_use() == 6
+        keep = fl                                        # a handle that outlives the extractor (DescriptorPool.h:71-75)
+        sp.close()                                       # two submissions pending: must neither crash nor leak
+        del fl, fr, keep
+        gc.collect()
+    sp = SuperPoint(weights_dir["sp_path"], 300, 0.005, 4, max_batch=2)
+    assert sp.initialize()
+    assert not sp.ring_create(99, h, w, 1)               # bad depth: no ring, and ring_host says so instead of segfaulting
+    with pytest.raises(RuntimeError):
+        sp.ring_host(0, 0)
+    assert sp.ring_create(1, h, w, 1)
+    with pytest.raises(IndexError):
+        sp.ring_host(5, 0)
+    sp.close()

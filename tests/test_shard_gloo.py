@@ -74,3 +74,63 @@ def test_dist_env_device_pin_and_backend_override(monkeypatch):
     assert dist_env() == (3, 3, 8, True, "nccl")                 # one process per GPU: device = LOCAL_RANK, RCCL
     monkeypatch.setenv("SUPERSLAM_HIP_DEVICE", "0"); monkeypatch.setenv("SUPERSLAM_DIST_BACKEND", "gloo")
     assert dist_env() == (3, 0, 8, True, "gloo")                 # the one-GPU multi-rank rehearsal (tests/test_gpu_multirank_rehearsal.py)
+
+
+# ---- `python script.py --gpus N` without a launcher (VERDICT r03 "do this" 3) -----------------------------------------
+def test_launcher_command_line_is_the_drivers_form():
+    import sys
+
+    from superslam_amd.shard import launcher_command
+
+    cmd = launcher_command("/x/bench.py", ["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29555)
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", "29555", "/x/bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    free = launcher_command("/x/bench.py", [], 2)
+    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+
+
+def test_relaunch_only_when_no_launcher_is_around(monkeypatch):
+    from superslam_amd import shard
+
+    calls = []
+    monkeypatch.setattr(os, "execvpe", lambda f, a, e: calls.append((f, a, e)))
+    monkeypatch.delenv("RANK", raising=False)
+    shard.relaunch_under_launcher_if_needed(1, "/x/bench.py", ["--gpus", "1"])
+    assert not calls                                              # N = 1: plain process, as the driver runs it
+    shard.relaunch_under_launcher_if_needed(8, "/x/bench.py", ["--gpus", "8", "--steps", "3"])
+    assert len(calls) == 1
+    f, a, e = calls[0]
+    assert a[1:7] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr"] and a[-5:] == ["/x/bench.py", "--gpus", "8", "--steps", "3"]
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("RANK", "3")
+    shard.relaunch_under_launcher_if_needed(8, "/x/bench.py", ["--gpus", "8"])
+    assert len(calls) == 1                                        # already one of the launcher's ranks: no second exec
+
+
+def test_plain_invocation_with_gpus_2_really_runs_two_ranks(tmp_path):
+    """End to end on CPU: a script that uses the same three helpers as bench.py (relaunch, dist_env, init_process_group), started as
+    `python script.py --gpus 2` with no launcher, comes out as two gloo ranks of which rank 0 prints one line."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two.py"
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {root!r})
+from superslam_amd.shard import relaunch_under_launcher_if_needed, dist_env, init_process_group, all_reduce_max_seconds
+relaunch_under_launcher_if_needed(2, os.path.abspath(__file__), sys.argv[1:])
+import torch.distributed as dist
+rank, dev, world, under, backend = dist_env()
+init_process_group(backend, dev)
+t = all_reduce_max_seconds(1.0 + rank)
+if rank == 0:
+    print("RESULT", world, under, t, sys.argv[1:], flush=True)
+dist.barrier(); dist.destroy_process_group()
+""")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SUPERSLAM_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(script), "--gpus", "2"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert lines == ["RESULT 2 True 2.0 ['--gpus', '2']"], (lines, r.stderr[-2000:])
