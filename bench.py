@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 H, W = 376, 1376
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 HBM_PEAK_GBS = 8000.0
+PATH_VS_PATH_BAR = 3e-2     # |d mscores0| between two fp16 paths (tests/_lgcmp.py derives it; tests/test_parity_margins.py pins the two together)
 
 
 def sp_flops_per_image(h, w):
@@ -131,8 +132,9 @@ def self_check(torch, np, fe, chunk, stream, wdir, max_kp):
     """After the timed region: the batched call's outputs for one chunk against the PER-PAIR path (a second pair of handles sized
     like the reference's per-frame use: SuperPoint max_batch = 2, LightGlue max_pairs = 1 - different kernel variants: latency-mode
     attention / FFN, one workgroup round).  Keypoints, scores and counts must be bit-identical, descriptors within 1 fp16 ulp,
-    matches0 / mscores0 within the matcher bars of tests/_lgcmp.py (>= 99 % of the rows, |d mscores0| <= 2e-2 where the mutual
-    flag agrees).  The headline number is only meaningful if the batch it times computes what the per-frame path computes."""
+    matches0 / mscores0 within the matcher bars of tests/_lgcmp.py (>= 99 % of the rows, |d mscores0| <= PATH_VS_PATH_BAR = 3e-2
+    where the mutual flag agrees: this compares two fp16 paths, each of which may sit 2e-2 from the oracle - the 2e-2 bar is the
+    path-vs-ORACLE tolerance of SURVEY 8(c), and the tests that compare with the oracle keep it).  The headline number is only meaningful if the batch it times computes what the per-frame path computes."""
     from superslam_amd import FrontEndBatch, LightGlue, SuperPoint
 
     P = fe.pairs
@@ -161,7 +163,7 @@ def self_check(torch, np, fe, chunk, stream, wdir, max_kp):
         ma, sa = m0[p, :k0], s0[p, :k0]
         mb, sb = fe1.matches0.cpu().numpy()[0, :k0], fe1.mscores0.cpu().numpy()[0, :k0]
         ds = np.abs(sa - sb)
-        same = ~(((sa > 0) != (sb > 0)) & (ds > 2e-2))
+        same = ~(((sa > 0) != (sb > 0)) & (ds > PATH_VS_PATH_BAR))
         res["matches_rows"] += k0
         res["matches_equal_rows"] += int((ma == mb).sum())
         res["mutual_flips"] += int((~same).sum())
@@ -173,7 +175,9 @@ def self_check(torch, np, fe, chunk, stream, wdir, max_kp):
     res["min_pair_agreement"] = round(res["min_pair_agreement"], 4)
     res["agreement"] = round(res["matches_equal_rows"] / max(1, res["matches_rows"]), 5)
     res["ok"] = bool(res["kp_bit_identical"] == P and res["desc_max_ulp"] <= 1 and res["agreement"] >= 0.99
-                     and res["mutual_flips"] <= max(1, int(0.005 * res["matches_rows"])) and res["mscores_maxd"] <= 2e-2)
+                     and res["mutual_flips"] <= max(1, int(0.005 * res["matches_rows"])) and res["mscores_maxd"] <= PATH_VS_PATH_BAR)
+    res["mscores_bar"] = PATH_VS_PATH_BAR
+    res["mscores_margin"] = round(PATH_VS_PATH_BAR / max(res["mscores_maxd"], 1e-9), 3)
     return res
 
 
@@ -411,10 +415,12 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
             if pj.get("pairs_per_call", pj.get("pairs_per_step")) == P and pj.get("headline_launches_only"):
                 traffic = pj.get("hbm_bytes_per_launch")
                 cur = hashlib.sha256(open(os.path.join(ROOT, "superslam_amd", "csrc", "conv_pp.hip"), "rb").read()).hexdigest()[:16]
-                traffic_source = {"file": "profiles/pmc_conv1ab.json", "collected_by": "scripts/pmc_traffic.sh (two separate rocprofv3 --pmc passes "
-                                  "over `bench.py --headline-only`, FETCH_SIZE x2-corrected + WRITE_SIZE per MI355X_MICROARCH.md); NOT measured in this run",
-                                  "collected_at": pj.get("collected_at"), "kernel_source_sha16_then": pj.get("conv_pp_sha16"),
-                                  "kernel_source_sha16_now": cur, "kernel_source_unchanged": pj.get("conv_pp_sha16") == cur}
+                # a FLAT string: the driver's record flattens `roofline` and dropped the nested dict round 3 used
+                traffic_source = ("READ from profiles/pmc_conv1ab.json, NOT measured in this run; collected " + str(pj.get("collected_at"))
+                                  + " by scripts/pmc_traffic.sh (two separate rocprofv3 --pmc passes over `bench.py --headline-only`, "
+                                  "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md); conv_pp.hip sha16 then "
+                                  + str(pj.get("conv_pp_sha16")) + " now " + cur
+                                  + (" (kernel source unchanged)" if pj.get("conv_pp_sha16") == cur else " (KERNEL SOURCE CHANGED since the collection)"))
         except Exception:
             traffic, traffic_source = None, None
     alg_bytes = B * (H * W + (H // 2) * (W // 2) * 64 * 2)   # u8 image in, pooled fp16 64-ch map out

@@ -3,26 +3,71 @@
 matches0 must agree on >= 99 % of the rows.  mscores0 is exp(max_j S_ij) for MUTUAL rows and exactly 0 otherwise
 (filter_matches): a near-tie whose mutual flag differs between the fp16 path and the oracle moves the score by its whole
 value although nothing is wrong numerically - such rows are counted (`flips`, <= 0.5 % of the rows, at least 1 allowed) and
-the 2e-2 bar applies to the rows whose flag agrees."""
+the mscores0 bar applies to the rows whose flag agrees.
+
+Two bars, and why they differ (VERDICT r03 "do this" 4):
+  * PATH_VS_ORACLE_BAR = 2e-2: an fp16 path against the fp64 oracle / the golden fixtures / the transformers port - SURVEY 8(c)'s
+    tolerance.  Worst case measured over every oracle comparison of the suite: 0.0133 (profiles/parity_report.json); an fp16 residual
+    stream alone costs 0.0138 on the 600 x 600 fixture (DESIGN item 25), so this bar has ~1.45x of margin and is not ours to move.
+  * PATH_VS_PATH_BAR = 3e-2: two DIFFERENT fp16 evaluations of the same problem (batch kernels vs per-pair kernels, translated /
+    permuted inputs, different batch slots).  Each is an independent fp16 perturbation of the oracle's answer; each may sit up to
+    2e-2 from it, so the triangle inequality allows 4e-2 between them; with the measured path-vs-oracle worst case e = 0.0133-0.0170
+    the realistic spread is 2e = 0.027-0.034.  Round 3 compared two paths against the ORACLE's 2e-2 and measured 0.01993 / 0.0194 /
+    0.02038: the noise floor of the comparison, not a margin.  3e-2 is the sum rule tests/test_gpu_lightglue_layers.py has used
+    since round 2; bench.py's self_check uses the same constant (tests/test_parity_margins.py pins the two together).
+MIN_MARGIN: every committed measurement must sit at least 1.25x under its bar (bar / measured), checked on CPU against
+profiles/parity_report.json - a bar that is being grazed fails the CPU suite before it can turn a GPU run red for a non-bug."""
 import numpy as np
 
 AGREEMENT_BAR = 0.99
-MSCORE_BAR = 2e-2
+PATH_VS_ORACLE_BAR = 2e-2
+PATH_VS_PATH_BAR = 3e-2
+MSCORE_BAR = PATH_VS_ORACLE_BAR          # historical name
 FLIP_FRACTION = 0.005
+MIN_MARGIN = 1.25
+
+# entries of the parity report that compare two fp16 paths with each other (everything else with an mscores figure is path vs oracle)
+PATH_VS_PATH_ENTRIES = {"batch128_vs_per_frame": "mscores_maxd", "lg_batch64_vs_single": "mscores_maxd", "bench_self_check": "mscores_maxd",
+                        "lg_translation_invariance": "mscores_maxd", "lg_permutation_equivariance": "mscores_maxd"}
 
 
-def compare(m, s, m_ref, s_ref):
+def compare(m, s, m_ref, s_ref, bar=PATH_VS_ORACLE_BAR):
     m, s, m_ref, s_ref = (np.asarray(a) for a in (m, s, m_ref, s_ref))
     ds = np.abs(s - s_ref)
     # a flip = the mutual flag differs AND the score moved by more than the bar (exp(max) of a hopeless row underflows to 0 on
     # the GPU and to a denormal in the fp64 oracle: same flag for every practical purpose)
-    same = ~(((s > 0) != (s_ref > 0)) & (ds > MSCORE_BAR))
+    same = ~(((s > 0) != (s_ref > 0)) & (ds > bar))
     return {"agreement": float((m == m_ref).mean()), "mismatched_rows": int((m != m_ref).sum()), "mutual_flips": int((~same).sum()),
             "mscores_maxd": float(ds[same].max()) if same.any() else 0.0, "mscores_maxd_all": float(ds.max()) if len(ds) else 0.0,
-            "rows": int(len(m))}
+            "rows": int(len(m)), "mscores_bar": bar}
 
 
-def check(c, mscore_bar=MSCORE_BAR):
+def check(c, mscore_bar=None):
+    bar = c.get("mscores_bar", PATH_VS_ORACLE_BAR) if mscore_bar is None else mscore_bar
     assert c["agreement"] >= AGREEMENT_BAR or c["mismatched_rows"] <= 1, c
     assert c["mutual_flips"] <= max(1, int(FLIP_FRACTION * c["rows"])), c
-    assert c["mscores_maxd"] <= mscore_bar, c
+    assert c["mscores_maxd"] <= bar, c
+
+
+def margins(report):
+    """{entry.key: (measured, bar, bar / measured)} for every mscores0 figure of a parity report."""
+    out = {}
+    for name, e in report.items():
+        if not isinstance(e, dict):
+            continue
+        for key, v in e.items():
+            if not key.startswith("mscores_maxd") or key == "mscores_maxd_all" or not isinstance(v, (int, float)):
+                continue
+            paths = PATH_VS_PATH_ENTRIES.get(name) == key
+            bar = PATH_VS_PATH_BAR if paths else PATH_VS_ORACLE_BAR
+            out[f"{name}.{key}"] = (float(v), bar, float("inf") if v == 0 else bar / float(v))
+    return out
+
+
+def annotate(report):
+    """Write bar and margin next to every mscores0 figure (called when the GPU session's report is saved)."""
+    for k, (v, bar, m) in margins(report).items():
+        name, key = k.rsplit(".", 1)
+        report[name][key + "_bar"] = bar
+        report[name][key + "_margin"] = round(m, 3) if m != float("inf") else None
+    return report

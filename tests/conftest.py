@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(1, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):
@@ -52,6 +54,9 @@ def parity_report():
     yield rep
     if not rep:
         return
+    import _lgcmp
+
+    _lgcmp.annotate(rep)     # bar and margin (bar / measured) next to every mscores0 figure
     for d in (os.path.join(ROOT, "gpurun_out"),):
         try:
             os.makedirs(d, exist_ok=True)

@@ -80,7 +80,8 @@ def test_batch128_equals_the_per_frame_path_image_by_image(batch_run, weights_di
             assert _lib.lib().sship_desc_to_host(f.descriptors.data, n, 256, got.ctypes.data) == 0
             worst_ulp = max(worst_ulp, int(_ulp16(batch_run["desc"][i, :n], got.astype(np.float16)).max()))
         res = lg1.match(fl.keypoints, fl.descriptors, fr.keypoints, fr.descriptors)
-        c = _lgcmp.compare(batch_run["m0"][p, :K], batch_run["s0"][p, :K], res.matches0, res.mscores0)
+        # two fp16 paths (batch kernels vs per-pair kernels): the path-vs-path bar (tests/_lgcmp.py)
+        c = _lgcmp.compare(batch_run["m0"][p, :K], batch_run["s0"][p, :K], res.matches0, res.mscores0, bar=_lgcmp.PATH_VS_PATH_BAR)
         rows += c["rows"]; equal_rows += c["rows"] - c["mismatched_rows"]; flips += c["mutual_flips"]
         maxd = max(maxd, c["mscores_maxd"]); min_agree = min(min_agree, c["agreement"])
         _lgcmp.check(c)
