@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off fit of the GELU constants of superslam_amd/csrc/lg_kernels.hip (kGeluQ0..4): gelu(y) = y sigmoid(y Q(y^2)), Q fitted by
+"""One-off fit of the GELU constants of superslam_amd/csrc/lg_ffn.h (kGeluQ0..4): gelu(y) = y sigmoid(y Q(y^2)), Q fitted by
 Lawson-reweighted least squares to the minimax relative error against y Phi(y) (scipy).  The result is pasted into the kernel source;
 tests/test_lightglue_known_answers.py re-checks the pasted constants against erf."""
 import numpy as np

@@ -7,6 +7,7 @@
 
 #include "igemm.h"
 #include "kernels.h"
+#include "lg_ffn.h"
 
 namespace sship {
 
@@ -527,43 +528,12 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
 //     the next layer's Wqkv after a CrossBlock FFN, final_proj + matchability after the last one) runs in the same
 //     launch on the 64-token tile that is already on chip: wave w owns NEXT_MT*32 output rows, K = 256, epilogue =
 //     the igemm epilogue of that projection (EpiHeads / plain fp16).
-constexpr int kFfnLd = 520;
 // compile-time ablation of the FFN kernel (build.py --variant -DSSHIP_FFN_ABL=n): 1 skip ffn.0 MFMAs, 2 skip LN/GELU
 // math, 4 skip ffn.3, 8 skip the fused projection's MFMAs, 16 skip input staging, 32 skip the projection epilogue,
 // 64 skip the residual update.  (Run-time flags put a branch in front of every GELU element.)
 #ifndef SSHIP_FFN_ABL
 #define SSHIP_FFN_ABL 0
 #endif
-typedef float f2_t __attribute__((ext_vector_type(2)));
-// GELU (exact-erf form, nn.GELU()) on two values.  gelu(y) = y Phi(y) = y sigmoid(g(y)) with g = logit(Phi), an odd function:
-// g(y) = y Q(y^2), Q a degree-4 polynomial fitted (minimax on the relative error over |y| <= 12, scripts/fit_gelu.py) to
-//   max |gelu_approx - y Phi(y)| = 7.0e-6,  relative 4.4e-5 where |gelu| >= 0.05
-// i.e. under a fifth of half an fp16 ulp of the result, which is rounded to fp16 right after (tests/test_lightglue_known_answers.py
-// evaluates these very constants in fp32 against erf).  Q > 0 everywhere, so the form saturates correctly (y -> +inf: y,
-// y -> -inf: -0).  Cost per pair of values: 8 packed fp32 ops + 2 v_exp + 2 v_rcp; the Abramowitz-Stegun erfc form it
-// replaces (|err| 1.5e-7) took 16 packed ops + 4 transcendentals + 2 max, and the GELU phase is VALU-issue bound.
-// The coefficients carry the factor -log2(e) so that sigmoid(g) = 1 / (1 + exp2(y q(y^2))).
-constexpr float kGeluQ0 = -2.301893292e+00f, kGeluQ1 = -1.054467824e-01f, kGeluQ2 = 4.423903354e-04f, kGeluQ3 = 7.747288073e-05f,
-                kGeluQ4 = -2.787147429e-06f;
-__device__ __forceinline__ f2_t gelu2(f2_t y) {
-  const f2_t s = y * y;
-  f2_t q = s * kGeluQ4 + kGeluQ3;
-  q = q * s + kGeluQ2;
-  q = q * s + kGeluQ1;
-  q = q * s + kGeluQ0;
-  const f2_t t = y * q;
-  const f2_t d = {1.0f + __builtin_amdgcn_exp2f(t[0]), 1.0f + __builtin_amdgcn_exp2f(t[1])};
-  const f2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  return y * r;
-}
-struct FfnTail {
-  int ntiles;                               // token tiles of the launch (the kernel is persistent: tile = blockIdx.x + k gridDim.x)
-  IgemmArgs proj;          // epilogue arguments of the fused projection (wpack/bias/outputs/rope/np/flags/cout/H)
-  unsigned long long* trace;  // SSHIP_FFN_TRACE: [workgroup][wave][12] shader-clock stamps of the workgroup's 2nd tile
-  const float* match_w;    // final block only: matchability weights [256] ...
-  float match_b;
-  float* logsig;           // ... -> logsigmoid(z) per token
-};
 // NT = 32-token N-tiles per workgroup.  Every weight fragment a wave streams from L2 feeds NT MFMAs; at NT = 2 the
 // three GEMMs need 64 B/clk/CU of L2 -> L1 bandwidth to keep the matrix pipe busy (= the TCP's peak, so the kernel
 // was bound by the weight stream: 1.18 MB per 64 tokens).  NT = 4 halves the stream per token (throughput batches);
@@ -1416,6 +1386,14 @@ static bool use_ffn4(int tokens) {
   return tokens % 64 == 0 && tokens / 64 >= 2 * cu_count();
 }
 
+// SUPERSLAM_HIP_FFN=16: the 16-wave kernel of lg_ffn16.hip for every launch it applies to; default: for throughput batches
+// (at least four 32-token N-tiles per CU)
+static bool use_ffn16(int tokens) {
+  static const int env = getenv("SUPERSLAM_HIP_FFN") ? atoi(getenv("SUPERSLAM_HIP_FFN")) : 0;
+  if (env == 16) return true;
+  if (env == 4 || env == 8) return false;
+  return false;   // until measured
+}
 static bool trace_on_is8() { return false; }
 // SSHIP_FFN_TRACE=1 with the 4-wave kernel: mean shader-clock duration of every phase of a workgroup's second tile
 static void ffn4_trace_report(unsigned long long* dev, int nwg, int next_mt, hipStream_t s) {
@@ -1472,6 +1450,10 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
   const int mt = next->cout / 256;  // rows per wave / 32: 768 -> 3, 512 -> 2, 256 -> 1
+  if (use_ffn16(tokens) && ffn16_applicable(tokens, mt, heads)) {
+    (void)launch_lg_ffn16(tokens, mt, heads, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    return;
+  }
   if (use_ffn4(tokens) && !trace_on_is8()) {
     t.ntiles = tokens / 64;
     if (heads && mt == 3) (void)launch_ffn4<3, true, false>(tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);

@@ -416,11 +416,11 @@ def test_raw_checkpoint_key_layout_round_trip():
 
 
 def test_kernel_gelu_constants_against_erf():
-    """The HIP kernels evaluate GELU as y * sigmoid(y Q(y^2)) (lg_kernels.hip, gelu2): parse the constants from the kernel
+    """The HIP kernels evaluate GELU as y * sigmoid(y Q(y^2)) (csrc/lg_ffn.h, gelu2): parse the constants from the kernel
     source, evaluate the same formula in fp32 and compare with the exact erf form over the whole useful range."""
     import re
 
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "superslam_amd", "csrc", "lg_kernels.hip")).read()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "superslam_amd", "csrc", "lg_ffn.h")).read()
     q = [np.float32(re.search(rf"kGeluQ{i} = (-?[0-9.]+e[+-][0-9]+)f", src).group(1)) for i in range(5)]
     y = np.linspace(-12, 12, 200001).astype(np.float32)
     s = y * y
