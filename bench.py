@@ -163,7 +163,7 @@ def self_check(torch, np, fe, chunk, stream, wdir, max_kp):
         ma, sa = m0[p, :k0], s0[p, :k0]
         mb, sb = fe1.matches0.cpu().numpy()[0, :k0], fe1.mscores0.cpu().numpy()[0, :k0]
         ds = np.abs(sa - sb)
-        same = (sa > 1e-4) == (sb > 1e-4)     # a flip = the mutual flag differs (tests/_lgcmp.py: FLAG_EPS)
+        same = ~(((sa > 0) != (sb > 0)) & (ds > 1e-3))     # a flip = the mutual flag differs and the score is not negligible (tests/_lgcmp.py: FLIP_MIN)
         res["matches_rows"] += k0
         res["matches_equal_rows"] += int((ma == mb).sum())
         res["mutual_flips"] += int((~same).sum())

@@ -1527,20 +1527,27 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
     _Float16 *xs = x + tok * 256, *qs = q + tok * 256, *ks = k + tok * 256, *vs = vt + tok * 256, *cs = ctx + tok * 256;
     const float* rs = rope + tok * 64;
     const int* ls = lens + 2 * p0;
+    // what each FFN launch streams (w0, w3, the fused projection): handed to the launch BEFORE it as a prefetch hint (latency mode)
+    auto self_w = [&](int i, const ConvW** o) { o[0] = &w->ffn0_s[i]; o[1] = &w->ffn3_s[i]; o[2] = &w->cqkv_t[i]; };
+    auto cross_w = [&](int i, const ConvW** o) { o[0] = &w->ffn0_c[i]; o[1] = &w->ffn3_c[i]; o[2] = i + 1 < kLgLayers ? &w->qkv_t[i + 1] : &w->final_t; };
+    const ConvW* pf[3];
+    self_w(0, pf);
     if (igemm_qkv0) SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st));
-    else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st));
+    else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st, pf));
     for (int i = 0; i < n_layers; ++i) {
       // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
       launch_lg_attention(qs, ks, vs, ls, ds, false, cs, st, shared_gpu);
+      cross_w(i, pf);
       launch_lg_ffn(w->ffn0_s[i], w->ffn3_s[i], w->ln_g_s[i], w->ln_b_s[i], cs, xs, ds, &w->cqkv_t[i], true, /*rope_segs=*/0,
-                    /*t_seg=*/1, rs, qs, ks, vs, nullptr, nullptr, 0.f, nullptr, st);
+                    /*t_seg=*/1, rs, qs, ks, vs, nullptr, nullptr, 0.f, nullptr, st, pf);
       // CrossBlock (qk shared by both directions; sequence s attends to s^1); its FFN emits the next layer's Wqkv,
       // or final_proj + matchability after the last layer
       launch_lg_attention(qs, qs, vs, ls, ds, true, cs, st, shared_gpu);
-      if (i + 1 < kLgLayers)
+      if (i + 1 < kLgLayers) {
+        self_w(i + 1, pf);
         launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], cs, xs, ds, &w->qkv_t[i + 1], true, 2, 2, rs, qs, ks,
-                      vs, nullptr, nullptr, 0.f, nullptr, st);
-      else
+                      vs, nullptr, nullptr, 0.f, nullptr, st, pf);
+      } else
         launch_lg_ffn(w->ffn0_c[i], w->ffn3_c[i], w->ln_g_c[i], w->ln_b_c[i], cs, xs, ds, &w->final_t, false, 0, 0, rs, qs, ks, vs,
                       lg->md.as<_Float16>() + tok * 256, w->match_w, w->match_b, lg->logsig.as<float>() + tok, st);
     }

@@ -103,12 +103,13 @@ hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope
                            const float* rope, _Float16* q, _Float16* k, _Float16* vt, hipStream_t s);
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,
                          bool cross, _Float16* ctx, hipStream_t s, bool shared_gpu = false);
+// prefetch (both launches below): up to three packed layers the NEXT FFN launch streams; latency mode pulls them into L2 with surplus workgroups
 hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int rope_segs, int t_seg, const float* rope, _Float16* q,
-                                _Float16* k, _Float16* vt, hipStream_t s);
+                                _Float16* k, _Float16* vt, hipStream_t s, const ConvW* const* prefetch = nullptr);
 void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
                    _Float16* x, LgDims d, const ConvW* next, bool heads, int rope_segs, int t_seg, const float* rope,
                    _Float16* q, _Float16* k, _Float16* vt, _Float16* out, const float* match_w, float match_b,
-                   float* logsig, hipStream_t s);
+                   float* logsig, hipStream_t s, const ConvW* const* prefetch = nullptr);
 void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hipStream_t s);
 void launch_lg_assign(const _Float16* md, const float* logsig, const int* lens, LgDims d, float* ws, float* pcol, int max_kp,
                       int32_t* matches0, float* mscores0, float thr, int stage, hipStream_t s);

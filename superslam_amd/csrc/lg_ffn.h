@@ -32,9 +32,15 @@ struct FfnTail {
   int ntiles;                               // token tiles of the launch (the kernel is persistent: tile = blockIdx.x + k gridDim.x)
   IgemmArgs proj;          // epilogue arguments of the fused projection (wpack/bias/outputs/rope/np/flags/cout/H)
   unsigned long long* trace;  // SSHIP_FFN_TRACE: [workgroup][wave][12] shader-clock stamps of the workgroup's 2nd tile
+  int trace_it;               // ... or of tile iteration SSHIP_FFN_TRACE_IT (0 = first: latency mode has one tile per workgroup)
   const float* match_w;    // final block only: matchability weights [256] ...
   float match_b;
   float* logsig;           // ... -> logsigmoid(z) per token
+  // latency mode (k_lg_ffn with a few workgroups): workgroups n_main .. gridDim.x - 1 do no FFN work - they pull the NEXT launch's packed
+  // weights (up to three regions) into the L2 of the XCD they happen to run on, so that launch streams from L2 instead of HBM / MALL
+  int n_main;              // 0: no prefetch workgroups (gridDim.x workgroups walk the tiles)
+  const void* pf_ptr[3];
+  int pf_bytes[3];
 };
 
 // lg_ffn16.hip: the 16-wave, one-workgroup-per-CU form of the fused block (throughput batches)

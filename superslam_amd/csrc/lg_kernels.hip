@@ -545,7 +545,11 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
                                                 const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
   constexpr int NTOK = NT * 32;
-  constexpr int G0 = NT <= 2 ? 8 : 4;  // ffn.0 k-steps per register-prefetch group (acc takes 32 NT registers)
+  // ffn.0 k-steps per register-prefetch group.  Two groups are in flight: 4 k-steps x 2 M-tiles x 2 groups = 16 one-KB loads per wave.
+  // Round 4 (scripts/ubench/l2_stream.hip, profiles/r04_h_*): a CU streams an L2-resident weight set at 123-132 GB/s with 8 waves and
+  // 8-16 loads in flight per wave, and at 56-62 GB/s with 32 - the rate HALVES past 16 per wave.  Groups of 8 k-steps (32 in flight)
+  // are what held this kernel at 27-34 B/clk/CU in rounds 1-3.
+  constexpr int G0 = 4;
   constexpr int XBUF = NTOK * kFfnLd;  // halfs per token-tile buffer
   extern __shared__ __attribute__((aligned(16))) char ffn_smem[];
   _Float16* s_xbuf = reinterpret_cast<_Float16*>(ffn_smem);                                   // [NBUF][NTOK][kFfnLd]
@@ -574,16 +578,41 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     }
   };
   const int tile0 = blockIdx.x;
+  const int nwg = tail.n_main > 0 ? tail.n_main : (int)gridDim.x;  // workgroups that walk the tiles
+  if (tail.n_main > 0 && tile0 >= nwg) {
+    // Prefetch role (latency mode).  One pair's launch covers 38 of 256 CUs and every layer has its own
+    // 1.0-1.15 MB of weights (21 MB over the 18 blocks: no XCD's 4 MB L2 keeps them from one frame to the next), so each FFN launch used
+    // to stream its weights at HBM / MALL latency: 19-23 us for a launch whose arithmetic is 3 us.  The surplus workgroups of THIS
+    // launch read the NEXT launch's weights once per XCD - workgroup ids are dealt round-robin over the 8 XCDs, so prefetch
+    // workgroup p serves XCD (n_main + p) % 8 and takes slice p / 8 of the (gridDim.x - n_main) / 8 slices; a different mapping
+    // only changes which L2 gets warm, never a result.
+    const int p = tile0 - nwg, nsl = ((int)gridDim.x - nwg) >> 3, sl = p >> 3;
+    if (sl >= nsl) return;
+    unsigned acc = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const char* base = static_cast<const char*>(tail.pf_ptr[r]);
+      const int bytes = tail.pf_bytes[r];
+      if (!base) continue;
+#pragma unroll 4
+      for (int off = (sl * 512 + (int)threadIdx.x) * 16; off < bytes; off += nsl * 512 * 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + off);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+      }
+    }
+    if (acc == 0x9e3779b9u && tail.trace) tail.trace[0] = acc;  // keeps the loads alive; never true in practice and harmless if it is
+    return;
+  }
   if (tile0 >= tail.ntiles) return;
   stage_tile(tile0, s_xbuf, threadIdx.x >> 6, threadIdx.x & 63);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int it = 0;
 #pragma unroll 1
-  for (int tile = tile0; tile < tail.ntiles; tile += gridDim.x, ++it) {
+  for (int tile = tile0; tile < tail.ntiles; tile += nwg, ++it) {
   _Float16* s_x = s_xbuf + (NT <= 2 ? (it & 1) : 0) * XBUF;
   _Float16* s_xn = s_xbuf + (NT <= 2 ? ((it + 1) & 1) : 0) * XBUF;
-  const bool has_next = tile + (int)gridDim.x < tail.ntiles;
+  const bool has_next = tile + nwg < tail.ntiles;
   const size_t t0 = (size_t)tile * NTOK;
   // Everything below that does not depend on the tile (weight fragments, biases, LayerNorm parameters) is loop
   // invariant: LICM would hoist those loads out of the tile loop and spill hundreds of registers.  An opaque zero
@@ -600,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   const float* mwq = tail.match_w + zero;
   const _Float16* bfp = s_x + j * kFfnLd + hh * 8;  // B fragment of N-tile n, k-step ks: bfp + n*32*kFfnLd + ks*16
   auto stamp = [&](int slot) {
-    if (tail.trace && it == 1 && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
+    if (tail.trace && it == tail.trace_it && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
   };
   stamp(0);
   if constexpr (!PROJ) {
@@ -687,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   // every wave has passed the LayerNorm barriers, i.e. finished the previous tile: its buffer takes the next tile.
   // Issued here because no weight prefetch is in flight (an older DMA would sit in front of it in the in-order vmcnt
   // queue) and the GELU math + ffn.3 that follow cover the HBM latency.
-  if (NT <= 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);
+  if (NT <= 2 && has_next) stage_tile(tile + nwg, s_xn, wave, lane);
   // the residual operand (this lane's 16 x values per N-tile) is requested before the GELU math: its L2 round trip
   // used to sit between the ffn.3 loop and the barrier that opens the fused projection
   h4_t xres[4][NT];
@@ -724,24 +753,25 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     for (int r = 0; r < 16; ++r) ac2[n][r] = 0.f;
   {
     const _Float16* wp = w3q + (size_t)wave * (32 * 512) + lane * 8;  // packed [cb = wave][k16][mt = 0][lane][8]
-    h8_t a3[2][16];
+    // four groups of 8 k-steps, two in flight (16 loads per wave: see G0)
+    h8_t a3[2][8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
+    for (int i = 0; i < 8; ++i) a3[0][i] = *reinterpret_cast<const h8_t*>(wp + i * 512);
 #pragma unroll
-    for (int grp = 0; grp < 2; ++grp) {
+    for (int grp = 0; grp < 4; ++grp) {
       if (SSHIP_FFN_ABL & 4) break;
-      if (grp == 0) {
+      if (grp + 1 < 4) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a3[1][i] = *reinterpret_cast<const h8_t*>(wp + (16 + i) * 512);
+        for (int i = 0; i < 8; ++i) a3[(grp + 1) & 1][i] = *reinterpret_cast<const h8_t*>(wp + ((grp + 1) * 8 + i) * 512);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ks = grp * 16 + i;
+      for (int i = 0; i < 8; ++i) {
+        const int ks = grp * 8 + i;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const h8_t bf = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + ks * 16);
-          ac2[n] = mfma32(a3[grp][i], bf, ac2[n]);
+          ac2[n] = mfma32(a3[grp & 1][i], bf, ac2[n]);
         }
       }
     }
@@ -789,7 +819,27 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       constexpr int VMASK = decltype(vmask_c)::value;
       // weight fragments: two groups of GT k-steps in flight in registers, pinned above the MFMAs of the previous
       // group (a plain unrolled loop made hipcc wait for every fragment right before its MFMA: 28k clocks for 96 MFMAs)
-      constexpr int GT = NT <= 2 ? 4 : 2;
+      constexpr int GT = NEXT_MT >= 3 ? 2 : 4;  // 2 GT NEXT_MT <= 16 loads in flight per wave (see G0)
+      // rotary (cos, sin) quads of this lane's q / k rows and the q / k biases: requested HERE, consumed after the MFMA loop.  (Round 4:
+      // the generic igemm epilogue loaded them inside its store loops, behind its own stores in the in-order vmcnt queue - 9.8 k clocks
+      // for the Wqkv epilogue of a one-pair launch, profiles/r04_j_*.)  The q and the k tile of a wave cover the same head-local
+      // channels ((8 m + wave) * 32 mod 64 does not depend on m): one rotary set serves both.
+      constexpr int NQK = HEADS ? NEXT_MT - 1 : 0;   // M-tiles with the q / k epilogue (the last one is V)
+      const int rope_segs_t = pj.flags & 0xf;
+      float4 cs[4][NT], bqk[NQK > 0 ? NQK : 1][4];
+      if constexpr (HEADS) {
+        if (rope_segs_t > 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              cs[g][n] = *reinterpret_cast<const float4*>(pj.aux + (t0 + n * 32 + j) * 64 + ((wave * 32) & 63) + hh * 4 + g * 8 + zero);
+        }
+#pragma unroll
+        for (int m = 0; m < NQK; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bqk[m][g] = *reinterpret_cast<const float4*>(pj.bias + (m * 8 + wave) * 32 + hh * 4 + g * 8);
+      }
       h8_t at[2][GT][NEXT_MT];
 #pragma unroll
       for (int i = 0; i < GT; ++i)
@@ -824,7 +874,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
         }
       }
       stamp(8);
-      if (PROJ && NT <= 2 && has_next) stage_tile(tile + gridDim.x, s_xn, wave, lane);  // the epilogue covers the DMA
+      if (PROJ && NT <= 2 && has_next) stage_tile(tile + nwg, s_xn, wave, lane);  // the epilogue covers the DMA
       if (SSHIP_FFN_ABL & 32) return;
       if constexpr (HEADS) {
         const int NP = pj.np, nt32 = NP >> 5;
@@ -848,8 +898,40 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
               }
             }
           } else {
-            f16x_t (&one)[1][NT] = *reinterpret_cast<f16x_t (*)[1][NT]>(&ac3[m]);
-            EpiHeads::template run<1, NT>(pj, one, 0, (int)(t0 >> 5), j, R0, hh);
+            // q / k (or the shared qk of CrossBlock): bias, rotary on interleaved pairs, fp16, then lane ^ 32 pairing so that every lane
+            // owns whole 16-byte fragment units (k_lg_ffn4's epilogue): unit u = d / 8 -> [kstep u / 2][lane' = (u & 1) * 32 + token % 32][8]
+            const int seg = R0 >> 8, hd = (R0 >> 6) & 3;
+            const bool roped = seg < rope_segs_t;
+            _Float16* obase = static_cast<_Float16*>(seg == 0 ? pj.out0 : pj.out1);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const size_t token = t0 + n * 32;
+              const int sq = (int)(token / NP), kt = (int)(token - (size_t)sq * NP) >> 5;
+              _Float16* dst = obase + (((size_t)sq * 4 + hd) * nt32 + kt) * 2048;
+              unsigned lo[4], hi[4];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float4 bv = bqk[m < NQK ? m : 0][g];
+                float v0 = ac3[m][n][4 * g + 0] + bv.x, v1 = ac3[m][n][4 * g + 1] + bv.y;
+                float v2 = ac3[m][n][4 * g + 2] + bv.z, v3 = ac3[m][n][4 * g + 3] + bv.w;
+                if (roped) {
+                  const float4 c = cs[g][n];
+                  const float r0 = v0 * c.x - v1 * c.y, r1 = v1 * c.x + v0 * c.y;
+                  const float r2 = v2 * c.z - v3 * c.w, r3 = v3 * c.z + v2 * c.w;
+                  v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+                }
+                const h2_t p01 = {(_Float16)v0, (_Float16)v1}, p23 = {(_Float16)v2, (_Float16)v3};
+                lo[g] = __builtin_bit_cast(unsigned, p01);
+                hi[g] = __builtin_bit_cast(unsigned, p23);
+              }
+#pragma unroll
+              for (int gp = 0; gp < 2; ++gp) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(lo[2 * gp], lo[2 * gp + 1], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(hi[2 * gp], hi[2 * gp + 1], false, false);
+                const int u = ((R0 & 63) >> 3) + 2 * gp + hh;
+                *reinterpret_cast<uint4*>(dst + (u >> 1) * 512 + (((u & 1) << 5) + j) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+              }
+            }
           }
         }
       } else {
@@ -873,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   stamp(9);
   if (NT > 2 && has_next) {  // single tile buffer: synchronous restage
     __syncthreads();
-    stage_tile(tile + gridDim.x, s_xn, wave, lane);
+    stage_tile(tile + nwg, s_xn, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -882,7 +964,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   }  // tile loop
 }
 template <int NEXT_MT, bool HEADS, int NT, bool PROJ, typename... A>
-static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
+static hipError_t launch_ffn_nt(int tokens, int extra_wg, hipStream_t s, A... args) {
   constexpr size_t smem = (size_t)(NT <= 2 ? 2 : 1) * NT * 32 * kFfnLd * 2 + 16 * NT * 32 * 4 + 1792 * 4;
   static_assert(smem <= 163840, "LDS budget");
   auto kern = k_lg_ffn<NEXT_MT, HEADS, NT, PROJ>;
@@ -890,7 +972,7 @@ static hipError_t launch_ffn_nt(int tokens, hipStream_t s, A... args) {
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr_rc != hipSuccess) return attr_rc;
   const int ntiles = tokens / (NT * 32);
-  hipLaunchKernelGGL(kern, dim3(ntiles < cu_count() ? ntiles : cu_count()), dim3(512), smem, s, args...);  // one persistent workgroup per CU
+  hipLaunchKernelGGL(kern, dim3((ntiles < cu_count() ? ntiles : cu_count()) + extra_wg), dim3(512), smem, s, args...);  // one persistent workgroup per CU (+ the prefetch workgroups of latency mode)
   return hipGetLastError();
 }
 // SSHIP_FFN_TRACE=1 (developer aid): mean shader-clock duration of every phase of a workgroup's second tile.
@@ -913,11 +995,11 @@ static void ffn_trace_report(unsigned long long* dev, int nwg, int next_mt, hipS
   fprintf(stderr, " | tile=%.0f clk\n", tot);
 }
 template <int NEXT_MT, bool HEADS, typename... A>
-static hipError_t launch_ffn(int nt, int tokens, hipStream_t s, A... args) {
+static hipError_t launch_ffn(int nt, int tokens, int extra_wg, hipStream_t s, A... args) {
   // 64-token tiles for throughput, 32-token tiles when the launch cannot even give half of the CUs a workgroup (a few
   // pairs: twice the workgroups in flight, half the MFMA work per weight stream).  128 tokens measured 9 % slower end to
   // end (1.25 tiles per CU at 32 pairs, single tile buffer) and no longer fits the registers: not instantiated.
-  return nt == 1 ? launch_ffn_nt<NEXT_MT, HEADS, 1, false>(tokens, s, args...) : launch_ffn_nt<NEXT_MT, HEADS, 2, false>(tokens, s, args...);
+  return nt == 1 ? launch_ffn_nt<NEXT_MT, HEADS, 1, false>(tokens, extra_wg, s, args...) : launch_ffn_nt<NEXT_MT, HEADS, 2, false>(tokens, extra_wg, s, args...);
 }
 // ---------------------------------------------------------------------------------------------------
 // k_lg_ffn4: the same fused block with FOUR waves per workgroup and TWO workgroups per CU (throughput batches).
@@ -1423,10 +1505,23 @@ static void ffn4_trace_report(unsigned long long* dev, int nwg, int next_mt, hip
 }
 // next == nullptr: plain FFN.  Otherwise the projection `next` (packed with ct = 32 * next_mt rows per wave) runs on
 // the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
+// Latency mode's weight prefetch (FfnTail::n_main): the packed weights the NEXT FFN launch will stream, when the launch leaves CUs free
+static int ffn_prefetch_setup(FfnTail& t, int n_main, const ConvW* const* pf) {
+  static const bool off = getenv("SUPERSLAM_HIP_LG_PREFETCH") && atoi(getenv("SUPERSLAM_HIP_LG_PREFETCH")) == 0;  // A/B runs
+  constexpr int kPfWg = 64;  // 8 per XCD
+  if (off || !pf || n_main + kPfWg > cu_count()) return 0;
+  int k = 0;
+  for (int i = 0; i < 3; ++i)
+    if (pf[i] && pf[i]->w) { t.pf_ptr[k] = pf[i]->w; t.pf_bytes[k] = pf[i]->cout_pad * pf[i]->cin * 2; ++k; }
+  if (!k) return 0;
+  t.n_main = n_main;
+  return kPfWg;
+}
+
 void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const float* beta, const _Float16* ctx,
                    _Float16* x, LgDims d, const ConvW* next, bool heads, int rope_segs, int t_seg, const float* rope,
                    _Float16* q, _Float16* k, _Float16* vt, _Float16* out, const float* match_w, float match_b,
-                   float* logsig, hipStream_t s) {
+                   float* logsig, hipStream_t s, const ConvW* const* prefetch) {
   const int tokens = d.S * d.NP;
   FfnTail t{};
   static const int nt_env = getenv("SUPERSLAM_HIP_FFN_NT") ? atoi(getenv("SUPERSLAM_HIP_FFN_NT")) : 0;  // A/B: 1 | 2
@@ -1439,9 +1534,11 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
     if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)2 * cu_count() * 8 * 12 * 8);
     (void)hipMemsetAsync(trace_buf, 0, (size_t)2 * cu_count() * 8 * 12 * 8, s);
     t.trace = trace_buf;
+    static const int trace_it = getenv("SSHIP_FFN_TRACE_IT") ? atoi(getenv("SSHIP_FFN_TRACE_IT")) : 1;
+    t.trace_it = trace_it;
   }
   if (!next) {
-    (void)launch_ffn<0, false>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+    (void)launch_ffn<0, false>(nt, tokens, 0, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
     if (trace_on) ffn_trace_report(trace_buf, trace_wg, 0, s);
     return;
   }
@@ -1462,16 +1559,17 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
     if (trace_on) ffn4_trace_report(trace_buf, t.ntiles < 2 * cu_count() ? t.ntiles : 2 * cu_count(), mt, s);
     return;
   }
-  if (heads && mt == 3) (void)launch_ffn<3, true>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
-  else if (heads && mt == 2) (void)launch_ffn<2, true>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
-  else (void)launch_ffn<1, false>(nt, tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  const int extra = ffn_prefetch_setup(t, trace_wg, prefetch);  // trace_wg = the workgroups that walk the tiles
+  if (heads && mt == 3) (void)launch_ffn<3, true>(nt, tokens, extra, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else if (heads && mt == 2) (void)launch_ffn<2, true>(nt, tokens, extra, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
+  else (void)launch_ffn<1, false>(nt, tokens, extra, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
   if (trace_on) ffn_trace_report(trace_buf, trace_wg, mt, s);
 }
 
 // The first SelfBlock's Wqkv (no FFN in front of it): the FFN kernel's fused projection on its own - same persistent
 // tile loop, LDS-DMA staging, prefetched weight stream and tile-interleaved rows as the other 17 projections.
 hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int rope_segs, int t_seg, const float* rope, _Float16* q,
-                                _Float16* k, _Float16* vt, hipStream_t s) {
+                                _Float16* k, _Float16* vt, hipStream_t s, const ConvW* const* prefetch) {
   if (next.cout != 768) return hipErrorInvalidValue;
   const int tokens = d.S * d.NP;
   FfnTail t{};
@@ -1486,8 +1584,9 @@ hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int ro
     t.ntiles = tokens / 64;
     return launch_ffn4<3, true, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t);
   }
-  return nt == 1 ? launch_ffn_nt<3, true, 1, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t)
-                 : launch_ffn_nt<3, true, 2, true>(tokens, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t);
+  const int extra = ffn_prefetch_setup(t, t.ntiles < cu_count() ? t.ntiles : cu_count(), prefetch);
+  return nt == 1 ? launch_ffn_nt<3, true, 1, true>(tokens, extra, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t)
+                 : launch_ffn_nt<3, true, 2, true>(tokens, extra, s, (const _Float16*)x, nh, nf, nf, nf, nh, nf, x, t);
 }
 
 // ---------------------------------------------------------------------------------------------------
