@@ -163,10 +163,12 @@ def self_check(torch, np, fe, chunk, stream, wdir, max_kp):
         ma, sa = m0[p, :k0], s0[p, :k0]
         mb, sb = fe1.matches0.cpu().numpy()[0, :k0], fe1.mscores0.cpu().numpy()[0, :k0]
         ds = np.abs(sa - sb)
-        same = ~(((sa > 0) != (sb > 0)) & (ds > 1e-3))     # a flip = the mutual flag differs and the score is not negligible (tests/_lgcmp.py: FLIP_MIN)
+        flagdiff = (sa > 0) != (sb > 0)     # tests/_lgcmp.py: flips are judged by their size, mscores_maxd is taken where the flag agrees
+        same = ~flagdiff
         res["matches_rows"] += k0
         res["matches_equal_rows"] += int((ma == mb).sum())
-        res["mutual_flips"] += int((~same).sum())
+        res["mutual_flips"] += int((flagdiff & (ds > PATH_VS_PATH_BAR)).sum())
+        res["small_flips"] = res.get("small_flips", 0) + int((flagdiff & (ds <= PATH_VS_PATH_BAR)).sum())
         res["mscores_maxd"] = max(res["mscores_maxd"], float(ds[same].max()) if same.any() else 0.0)
         res["min_pair_agreement"] = min(res["min_pair_agreement"], float((ma == mb).mean()) if k0 else 1.0)
         res["matches_per_pair_path"] += int((mb >= 0).sum())

@@ -91,7 +91,7 @@ def main():
         np.savez(args.save, m=m, s=s)
     if args.ref:
         r = np.load(args.ref)
-        same = ~(((s > 0) != (r["s"] > 0)) & (np.abs(s - r["s"]) > 1e-3))
+        same = (s > 0) == (r["s"] > 0)
         out["vs_ref"] = {"agreement": float((m == r["m"]).mean()), "flips": int((~same).sum()), "rows": int(m.size),
                          "mscores_maxd": float(np.abs(s - r["s"])[same].max())}
     print(json.dumps(out), flush=True)

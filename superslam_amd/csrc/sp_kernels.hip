@@ -352,7 +352,8 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
   __shared__ unsigned long long s_key[kMaxKp];
   __shared__ int s_hist[256];
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_remaining, s_cnt;
+  __shared__ int s_remaining, s_cnt, s_done;
+  __shared__ unsigned long long s_out[1024];  // rank-sort output (K <= 1024)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int M = min(a.cand_count[b], a.cap);
   const int K = min(M, a.max_kp);
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
   };
   unsigned long long thresh = 0;
   if (M > K) {
-    if (tid == 0) { s_prefix = 0; s_remaining = K; }
+    if (tid == 0) { s_prefix = 0; s_remaining = K; s_done = 0; }
     for (int pass = 0; pass < 8; ++pass) {
       if (tid < 256) s_hist[tid] = 0;
       __syncthreads();
@@ -421,11 +422,16 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
             if (c + h[j] < rem && d == 255 - (4 * lane + j)) { c += h[j]; --d; }
           s_remaining = rem - c;
           s_prefix = (prefix << 8) | (unsigned)d;
+          // The boundary bin is taken WHOLE: every key whose top digits are >= this prefix is selected and there are exactly K of them -
+          // the remaining digits of the threshold are zeros and the later passes would only confirm it.  With ~7 k candidates this
+          // happens after 3-4 of the 8 passes (three barriers each; the kernel is one workgroup per image and barrier-bound).
+          if (rem - c == h[255 - d - 4 * lane]) s_done = pass + 1;
         }
       }
       __syncthreads();
+      if (s_done) break;
     }
-    thresh = s_prefix;
+    thresh = s_done ? s_prefix << (64 - 8 * s_done) : s_prefix;
   }
   if (tid == 0) s_cnt = 0;
   __syncthreads();
@@ -449,9 +455,30 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
       emit(i < M && k >= thresh, k);
     }
   }
+  __syncthreads();
+  const unsigned long long* sorted = s_key;
+  if (K <= 1024) {
+    // Rank sort (round 4): key i goes to position #{j : key_j > key_i} - the keys are distinct (the index is part of the key), every
+    // thread scans the K selected keys from LDS (all lanes read the same address: a broadcast, 16 bytes = two keys per read) and no
+    // barrier is needed until the scatter.  The bitonic network it replaces is 55 barrier rounds for K = 600 (P2 = 1024) in a kernel
+    // that is ONE workgroup per image: k_topk 34 us -> see profiles/r04_*; the order is the same total order, so the output is bit-identical.
+    if (tid < ((K + 1) & ~1) && tid >= K) s_key[tid] = 0ull;  // pad to an even count
+    __syncthreads();
+    if (tid < K) {
+      const unsigned long long mine = s_key[tid];
+      int rank = 0;
+      typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+      for (int jj = 0; jj < K; jj += 2) {
+        const ull2 two = *reinterpret_cast<const ull2*>(&s_key[jj]);
+        rank += (two[0] > mine) + (two[1] > mine);
+      }
+      s_out[rank] = mine;
+    }
+    __syncthreads();
+    sorted = s_out;
+  } else {
   int P2 = 1;
   while (P2 < K) P2 <<= 1;
-  __syncthreads();
   for (int i = K + tid; i < P2; i += 1024) s_key[i] = 0ull;
   __syncthreads();
   // bitonic sort, descending
@@ -467,8 +494,9 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
       __syncthreads();
     }
   }
+  }
   for (int i = tid; i < K; i += 1024) {
-    const unsigned long long k = s_key[i];
+    const unsigned long long k = sorted[i];
     const float score = __uint_as_float((unsigned)(k >> 32));
     const unsigned idx = (unsigned)(k & 0xffffffffu);
     const int h = idx / a.score_w, w = idx % a.score_w;
