@@ -60,7 +60,7 @@ def margins(report):
         if not isinstance(e, dict):
             continue
         for key, v in e.items():
-            if not key.startswith("mscores_maxd") or key == "mscores_maxd_all" or not isinstance(v, (int, float)):
+            if not key.startswith("mscores_maxd") or key == "mscores_maxd_all" or key.endswith(("_bar", "_margin")) or not isinstance(v, (int, float)):
                 continue
             paths = PATH_VS_PATH_ENTRIES.get(name) == key
             bar = PATH_VS_PATH_BAR if paths else PATH_VS_ORACLE_BAR
