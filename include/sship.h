@@ -241,6 +241,11 @@ int sship_lg_match_batch_device(sship_lg* lg, const float* kp_dev, const int* n_
 enum { SSHIP_LG_DEBUG_X = 0, SSHIP_LG_DEBUG_SIM = 1, SSHIP_LG_DEBUG_KPTS = 2, SSHIP_LG_DEBUG_ROPE = 3 };
 int sship_lg_debug_set_layers(sship_lg* lg, int n_layers);
 int sship_lg_debug_read(sship_lg* lg, int what, int index, int rows, int cols, float* out);
+/* Test-only: copy one encoder activation of the extractor's LAST call to the host as raw fp16 (channels-last [batch][h_l][w_l][c_l]),
+ * device-synchronising.  layer: 1 conv1b (+pool), 2 conv2a, 3 conv2b (+pool), 4 conv3a, 5 conv3b (+pool), 6 conv4a, 7 conv4b (the ids of
+ * sship_sp_bench_layer).  Used by the parity suite to compare single layers (e.g. the Winograd variant of conv2a / conv2b) with a CPU
+ * convolution of the previous layer's activation; the product never calls it.  `bytes` must not exceed the activation's size. */
+int sship_sp_debug_activation(sship_sp* sp, int layer, void* out_host, unsigned long long bytes);
 /* Match post-processing, src/LightGlue.cc:326-363: ascending i, skip -1, distance = 1 - score.
  * Returns the number of matches (>= 0). */
 int sship_filter_matches(const int32_t* matches0, const float* mscores0, int n0, int* query_idx,

@@ -6,7 +6,7 @@ src=$1; shift
 name=$(basename "$src" .hip)
 mkdir -p /tmp/kstats
 flags="-fno-honor-nans"
-case "$name" in lg_*) flags="$flags -Xclang -target-feature -Xclang -packed-fp32-ops";; esac
+case "$name" in lg_*|conv_wino) flags="$flags -Xclang -target-feature -Xclang -packed-fp32-ops";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $flags "$@" --cuda-device-only -S "$src" -o /tmp/kstats/$name.s
 python3 - /tmp/kstats/$name.s <<'PY'
 import re, subprocess, sys

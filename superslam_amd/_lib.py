@@ -65,6 +65,7 @@ _SIGS = {
     "sship_sp_ring_submit": (ip, [vp, ip]),
     "sship_sp_extract_batch_device": (ip, [vp, vp, ip, ip, ip, vp, vp, vp, vp]),
     "sship_sp_dense": (ip, [vp, vp, ip, ip, ip, vp, vp, vp, vp]),
+    "sship_sp_debug_activation": (ip, [vp, ip, vp, C.c_ulonglong]),
     "sship_lg_weights_load": (ip, [C.c_char_p, C.POINTER(vp)]),
     "sship_lg_weights_retain": (None, [vp]),
     "sship_lg_weights_release": (None, [vp]),

@@ -262,8 +262,9 @@ static int upload_conv(const float* w, const float* bias, int cout, int cin, int
 static void free_conv(ConvW& c) {
   if (c.w) (void)hipFree(c.w);
   if (c.w_q) (void)hipFree(c.w_q);
+  if (c.w_wino) (void)hipFree(c.w_wino);
   if (c.bias) (void)hipFree(c.bias);
-  c.w = nullptr; c.w_q = nullptr; c.bias = nullptr;
+  c.w = nullptr; c.w_q = nullptr; c.w_wino = nullptr; c.bias = nullptr;
 }
 // the same fragment order with a K chunk of `chunk` channels: [cout_blk][cin / chunk][ky][kx][k-step chunk / 16][m-tile][lane][8]
 static std::vector<_Float16> pack_conv(const float* w, int cout, int cin, int ks, int ct, int chunk, const std::vector<int>* row_map,
@@ -290,6 +291,26 @@ static std::vector<_Float16> pack_conv(const float* w, int cout, int cin, int ks
                   pk[o++] = (_Float16)v;
                 }
   return pk;
+}
+// Winograd F(2x2, 3x3) weights of a 64 -> 64 layer for conv_wino.hip: U_p = (G g G^T)[xi][nu], p = 4 xi + nu, computed in fp32 and
+// rounded to fp16, packed as MFMA A fragments [p 16][chunk 4][m 2][lane 64][8]: cout = 32 m + (lane & 31), cin = 16 chunk + 8 (lane >> 5) + e
+static int upload_wino(const float* w, ConvW& out) {
+  static const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  std::vector<_Float16> pk((size_t)16 * 4 * 2 * 512);
+  for (int co = 0; co < 64; ++co)
+    for (int ci = 0; ci < 64; ++ci) {
+      const float* g = w + ((size_t)co * 64 + ci) * 9;
+      float Gg[4][3], U[4][4];
+      for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 3; ++k) Gg[i][k] = G[i][0] * g[0 * 3 + k] + G[i][1] * g[1 * 3 + k] + G[i][2] * g[2 * 3 + k];
+      for (int i = 0; i < 4; ++i)
+        for (int jn = 0; jn < 4; ++jn) U[i][jn] = Gg[i][0] * G[jn][0] + Gg[i][1] * G[jn][1] + Gg[i][2] * G[jn][2];
+      const int m = co >> 5, chunk = ci >> 4, lane = (co & 31) + 32 * ((ci & 15) >> 3), e = ci & 7;
+      for (int p = 0; p < 16; ++p) pk[(((size_t)p * 4 + chunk) * 2 + m) * 512 + lane * 8 + e] = (_Float16)U[p >> 2][p & 3];
+    }
+  SSHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out.w_wino), pk.size() * sizeof(_Float16)));
+  SSHIP_HIP_CHECK(hipMemcpy(out.w_wino, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  return SSHIP_OK;
 }
 // second packing of a 128-input-channel 3x3 layer for conv_pp128.hip (64-row cout tiles, 32-channel chunks)
 static int upload_conv_q(const float* w, int cout, int cin, ConvW& out) {
@@ -643,6 +664,9 @@ static int conv_mode() {  // 1 ping-pong (default), 2 strip
   return v;
 }
 static hipError_t conv3(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s) {
+  // SUPERSLAM_HIP_CONV64=wino: conv2a / conv2b as Winograd F(2x2, 3x3) (conv_wino.hip; A/B)
+  static const bool wino = [] { const char* e = getenv("SUPERSLAM_HIP_CONV64"); return e && std::string(e) == "wino"; }();
+  if (wino && w.w_wino && sp_conv3x3_wino_fits(H, W, w.cin, w.cout)) return sp_conv3x3_wino(w.w_wino, w.bias, in, out, B, H, W, pool, s);
   return conv_mode() == 1 ? sp_conv3x3_pp(w, in, out, B, H, W, pool, s) : sp_conv3x3_strip(w, in, out, B, H, W, pool, s);
 }
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s);
@@ -758,6 +782,8 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
     // (conv_pp.hip), convDa keeps the k order the sparse descriptor head shares
     if (l.ks == 3 && std::string(l.name) != "convDa" && std::string(l.name) != "conv1b")
       if (int rc = upload_conv_q(w->data.data(), l.cout, l.cin, *l.dst)) return rc;
+    if (std::string(l.name) == "conv2a" || std::string(l.name) == "conv2b")
+      if (int rc = upload_wino(w->data.data(), *l.dst)) return rc;
     if (std::string(l.name) == "convDb")
       if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, 1, 32, sp->cDb32)) return rc;
     if (std::string(l.name) == "convPb") {  // the streaming kernel reads the plain matrix, [80][256] fp16 (sp_convs.hip: k_convpb_stream)
@@ -827,6 +853,15 @@ extern "C" void sship_sp_destroy(sship_sp* sp) {
   sp->pool = nullptr;
   if (sp->stream) (void)hipStreamDestroy(sp->stream);
   delete sp;
+}
+extern "C" int sship_sp_debug_activation(sship_sp* sp, int layer, void* out_host, unsigned long long bytes) {
+  bind_thread();
+  if (!sp || !out_host) return fail(SSHIP_ERR_INVALID, "sp_debug_activation: null argument");
+  DevBuf* bufs[8] = {nullptr, &sp->a1b, &sp->a2a, &sp->a2b, &sp->a3a, &sp->a3b, &sp->a4a, &sp->a4b};
+  if (layer < 1 || layer > 7 || !bufs[layer]->p || bytes > bufs[layer]->bytes) return fail(SSHIP_ERR_INVALID, "sp_debug_activation: bad layer / size");
+  SSHIP_HIP_CHECK(hipDeviceSynchronize());
+  SSHIP_HIP_CHECK(hipMemcpy(out_host, bufs[layer]->p, bytes, hipMemcpyDeviceToHost));
+  return SSHIP_OK;
 }
 extern "C" sship_pool* sship_sp_pool(sship_sp* sp) {
   bind_thread(); return sp ? sp->pool : nullptr; }

@@ -55,6 +55,7 @@ void launch_bgr2gray(const uint8_t* in, int n, uint8_t* out, hipStream_t s);
 // ---- sp_convs.hip : MFMA implicit-GEMM layers of SuperPoint ----
 struct ConvW {          // one packed conv / linear layer on the device
   _Float16* w = nullptr;  // packed A-fragment order (igemm.h)
+  _Float16* w_wino = nullptr;  // optional: Winograd F(2x2,3x3)-transformed weights of a 64 -> 64 3x3 layer (conv_wino.hip)
   _Float16* w_q = nullptr;  // optional second form: 64-row cout tiles over 32-channel chunks (conv_pp128.hip); convPb: the plain [80][256] matrix
   float* bias = nullptr;  // [cout_pad]
   int cin = 0, cout = 0, cout_pad = 0, ks = 1, ct = 64;
@@ -69,6 +70,9 @@ bool sp_conv3x3_pp128_fits(int B, int H, int W, int cin);
 hipError_t sp_conv3x3_pp128(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s);
 hipError_t sp_conv1ab_pp(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img, _Float16* out,
                          int B, int H, int W, hipStream_t s);
+// conv_wino.hip: Winograd F(2x2, 3x3) for 64 -> 64 channels (SUPERSLAM_HIP_CONV64=wino)
+bool sp_conv3x3_wino_fits(int H, int W, int cin, int cout);
+hipError_t sp_conv3x3_wino(const _Float16* upack, const float* bias, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s);
 hipError_t sp_conv1x1_f16(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s);
 // compute units of the current device (cached; persistent kernels launch one workgroup per CU). probe.hip
 int cu_count();

@@ -235,3 +235,25 @@ def test_two_matchers_on_shared_weights_run_concurrently(weights_dir):
     print("concurrent matchers: a", int((ref_a.matches0 >= 0).sum()), "matches, b", int((ref_b.matches0 >= 0).sum()))
     del fl, fr
     lg_a.close(); lg_b.close(); sp.close()
+
+
+def test_winograd_conv2a_conv2b_layer_parity():
+    """SUPERSLAM_HIP_CONV64=wino (csrc/conv_wino.hip; A/B, not the default): conv2a and conv2b + pool as Winograd F(2x2, 3x3), each compared
+    through the test-only sship_sp_debug_activation with a CPU convolution (fp32 math) of the SAME run's previous activation - a layer
+    test, not an end-to-end one.  fp16 transforms cost about 3x the direct kernel's rounding error (direct: 1e-3 on O(3) activations;
+    Winograd: 2-3.4e-3); bar 5e-3.  Sizes: two tiles per row with a partial one, an odd width, and the headline frame."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for size in ("64x96", "96x249", "376x1376"):
+        env = dict(os.environ, SUPERSLAM_HIP_CONV64="wino")
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "wino_check.py"), size, "2"], capture_output=True, text=True,
+                           timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        vals = dict(re.findall(r"wino\s+(conv2a|conv2b\+pool): max\|d\| ([0-9.e+-]+)", r.stdout))
+        assert set(vals) == {"conv2a", "conv2b+pool"}, r.stdout
+        assert "finite True" in r.stdout and "non-finite" not in r.stdout
+        for k, v in vals.items():
+            assert float(v) < 5e-3, (size, k, v)
