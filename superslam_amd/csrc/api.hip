@@ -596,6 +596,7 @@ struct sship_sp {
   // activations (channels-last fp16), sized for (B, H, W)
   int wsB = 0, wsH = 0, wsW = 0;
   DevBuf img, a1a, a1b, a2a, a2b, a3a, a3b, a4a, a4b, aPa, aDa, draw, logits, cand, cand_count;
+  const void* cand_zero_ptr = nullptr; int cand_zero_n = 0;  // cand_count[0 .. cand_zero_n) of this allocation are known to be zero (sp_select)
   DevBuf kp, cell_h, cell_w, n_dev, desc_stage, gray_in;
   PinBuf h_kp, h_n, h_img;
   int cap = 0;
@@ -725,7 +726,10 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
 static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float* kp_out, int* n_out, hipStream_t s) {
   int H2, W2, H4, W4, Hc, Wc;
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
-  SSHIP_HIP_CHECK(hipMemsetAsync(sp->cand_count.p, 0, (size_t)B * 4, s));
+  // The candidate counters are zeroed by k_topk once it has read them (a 5-us memset launch per call in latency mode otherwise);
+  // a memset is needed only for a fresh / regrown buffer or after a call that did not get as far as its k_topk launch.
+  if (sp->cand_zero_ptr != sp->cand_count.p || sp->cand_zero_n < B) SSHIP_HIP_CHECK(hipMemsetAsync(sp->cand_count.p, 0, (size_t)B * 4, s));
+  sp->cand_zero_ptr = sp->cand_count.p; sp->cand_zero_n = 0;
   NmsArgs a{};
   a.logits = sp->logits.as<float>(); a.ls = kLogitStride; a.B = B; a.H = Hc * 8; a.W = Wc * 8;
   a.radius = sp->cfg.nms_radius; a.thr_f = sp->thr_f; a.border = sp->cfg.remove_borders;
@@ -739,9 +743,10 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
   t.scale_x = static_cast<float>(W) / (Wc * 8);
   t.scale_y = static_cast<float>(H) / (Hc * 8);
   t.desc_h = Hc; t.desc_w = Wc; t.kp_xys = kp_out; t.cell_h = sp->cell_h.as<int>(); t.cell_w = sp->cell_w.as<int>();
-  t.n_out = n_out; t.n_cand_out = nullptr;
+  t.n_out = n_out; t.n_cand_out = nullptr; t.reset_count = a.cand_count;
   launch_topk(t, B, s);
   SSHIP_HIP_CHECK(hipGetLastError());
+  sp->cand_zero_n = B;
   g_timer.mark(g_profiling >= 2 ? "sp_extract_stereo:select/topk" : "sp_extract_stereo:select", s);
   return SSHIP_OK;
 }
@@ -953,6 +958,7 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
       case 11: return sp_conv1x1_f16(sp->cDb, aDa, sp->draw.as<_Float16>(), batch, Hc, Wc, s);
       case 12: {  // softmax + depth-to-space + NMS + threshold + candidate compaction (k_nms_tile) on the last logits
         if (hipError_t e = hipMemsetAsync(sp->cand_count.p, 0, (size_t)batch * 4, s)) return e;
+        sp->cand_zero_n = 0;  // this stage leaves its counts behind (stage 13 reads them): the next extraction clears them itself
         NmsArgs a{};
         a.logits = sp->logits.as<float>(); a.ls = kLogitStride; a.B = batch; a.H = Hc * 8; a.W = Wc * 8;
         a.radius = sp->cfg.nms_radius; a.thr_f = sp->thr_f; a.border = sp->cfg.remove_borders;

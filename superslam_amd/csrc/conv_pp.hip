@@ -356,7 +356,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
     // triple-buffered, the ds_reads of k-step i+2 are issued (and pinned) before the MFMAs of k-step i.
     h8_t fa[NBUF][MT], fb[NBUF][2];
     auto load_frags = [&](int idx, int buf) __attribute__((always_inline)) {
-      const int tap = idx >> 2, ks = idx & 3, ky = tap / 3, kx = tap - ky * 3;
+      // k order of one accumulator.  CIN = 64: tap-major, four k-steps per tap.  CIN = 128: the order of conv3x3_pp128w (32-channel
+      // half, kx, k-step, ky) - this kernel is the latency-mode stand-in for that one (sp_conv3x3_pp), and with the same fp16 operands
+      // entering the same fp32 accumulator in the same order the two are bit-identical: a frame extracted alone equals the same
+      // frame inside a 128-image batch (tests/test_gpu_bench_batch_parity.py, bench.py self_check).
+      const int h32 = idx / 18, r18 = idx - 18 * h32, t6 = r18 / 3;
+      const int ky = CIN == 128 ? r18 - 3 * t6 : (idx >> 2) / 3, kx = CIN == 128 ? t6 >> 1 : (idx >> 2) - 3 * ky;
+      const int tap = ky * 3 + kx, ks = CIN == 128 ? 2 * h32 + (t6 & 1) : idx & 3;
 #pragma unroll
       for (int m = 0; m < MT; ++m) fa[buf][m] = *reinterpret_cast<const h8_t*>(wc + ((tap * 4 + ks) * MT + m) * 512);
 #pragma unroll
@@ -564,8 +570,16 @@ hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int 
   if (w.cin == 64 && w.ct == 64) return pool ? launch_pp<64, 64, true, false>(a, s) : launch_pp<64, 64, false, false>(a, s);
   // 128 input channels: the 64-row-tile kernel over 32-channel chunks (conv_pp128.hip) when the layer carries that packing;
   // SUPERSLAM_HIP_CONV128=ct32 keeps the 32-row-tile kernel of this file (A/B runs)
-  static const bool ct32 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV128"); return e && std::string(e) == "ct32"; }();
-  if (w.cin == 128 && w.w_q && !ct32 && sp_conv3x3_pp128_fits(B, H, W, 128)) return sp_conv3x3_pp128(w, in, out, B, H, W, pool, s);
+  // (any other value, e.g. th16 / th8, switches the latency-mode choice below off)
+  static const std::string c128 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV128"); return std::string(e ? e : ""); }();
+  static const bool ct32 = c128 == "ct32";
+  // Latency mode (a frame or two per call): the 16 x 32-pixel tiles of conv_pp128.hip give conv4a at 2 x 47 x 172 cells 36 tiles = 18 x 2
+  // workgroups on 256 CUs, each running its two tiles' 2 x 4 x 144 MFMAs per wave back to back.  This file's kernel has 8-row tiles and
+  // 32-row cout tiles: 4x the workgroups, a quarter of the serial MFMA chain each.  One pair, us per launch (profiles/r04_q_*):
+  // conv3b 27.1 -> 22.6, conv4a / 4b 26.4 -> 12.6, convPa 27.2 -> 16.8.  Taken whenever the 16-row kernel would leave CUs without a workgroup.
+  const int tiles16 = B * ((W + 31) / 32) * ((H + 15) / 16);
+  const bool few_tiles = c128.empty() && w.ct == 32 && w.w && (tiles16 + 1) / 2 * (w.cout / 64) < cu_count();
+  if (w.cin == 128 && w.w_q && !ct32 && !few_tiles && sp_conv3x3_pp128_fits(B, H, W, 128)) return sp_conv3x3_pp128(w, in, out, B, H, W, pool, s);
   if (w.cin == 128 && w.ct == 32) return pool ? launch_pp<128, 32, true, false>(a, s) : launch_pp<128, 32, false, false>(a, s);
   return hipErrorInvalidValue;
 }

@@ -30,6 +30,7 @@ void launch_nms_tile(int loader, const NmsArgs& a, hipStream_t s);
 struct TopkArgs {
   const unsigned long long* cand;  // [B, cap]
   const int* cand_count;           // [B]
+  int* reset_count;                // [B] or null: the kernel zeroes the image's candidate counter once it has read it (the next call's NMS starts from 0 without a memset launch)
   int cap, max_kp;
   int score_w;                     // W of the score map (key idx = h*W + w)
   float scale_x, scale_y;          // input_w / score_w, input_h / score_h (float division on the host)

@@ -223,8 +223,8 @@ __global__ __launch_bounds__(512) void k_desc_head_gather(const _Float16* __rest
 // keypoint landed - its 3x3x128 input patch is gathered from the encoder output (a4b) - and feeds convDb + the two
 // normalisations above without leaving the CU.  600 keypoints of 8084 cells at KITTI size: 13x less convDa work
 // (it was the second most expensive head layer), and neither the 256-channel convDa map nor the descriptor grid is
-// written to HBM.  Arithmetic per output is the dense kernel's: same fp16 operands, same k order (64-channel chunk,
-// tap, k-step) into an fp32 accumulator that starts at the bias, ReLU, fp16.  reference: convert_superpoint_to_onnx.py:61-64,88-89.
+// written to HBM.  Arithmetic per output is the dense kernel's: same fp16 operands, same k order (64-channel chunk, 32-channel
+// half, kx, k-step, ky) into an fp32 accumulator that starts at the bias, ReLU, fp16.  reference: convert_superpoint_to_onnx.py:61-64,88-89.
 // A workgroup (8 waves) owns 64 keypoints of one image; wave w owns output channels [32w, 32w+32) of both layers and
 // streams its 72 KiB of convDa fragments from L2 (packed exactly as the dense conv kernels read them, ct = 32).
 // ---------------------------------------------------------------------------------------------------
@@ -256,9 +256,19 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
     for (int nn = 0; nn < 2; ++nn) { acc[nn][4 * g] = bv.x; acc[nn][4 * g + 1] = bv.y; acc[nn][4 * g + 2] = bv.z; acc[nn][4 * g + 3] = bv.w; }
   }
   const _Float16* wa = wda + (size_t)wave * (72 * 512) + lane * 8;  // [cb = wave][chunk][tap][kstep][lane][8]
-  h8_t fa[2][12];  // two groups of 12 fragments (one kernel row: 3 taps x 4 k-steps) in flight
+  // k order inside a 64-channel chunk: the dense kernels' (conv_pp.hip CIN = 128 / conv_pp128.hip: 32-channel half, kx, k-step, ky)
+  auto frag_of = [](int idx, int& tap, int& ks) __attribute__((always_inline)) {  // idx 0 .. 35 within the chunk
+    const int h32 = idx / 18, r18 = idx - 18 * h32, t6 = r18 / 3, ky = r18 - 3 * t6;
+    tap = ky * 3 + (t6 >> 1); ks = 2 * h32 + (t6 & 1);
+  };
+  auto wfrag = [&](int lin) __attribute__((always_inline)) {  // lin 0 .. 71 over both chunks
+    int tap, ks;
+    frag_of(lin % 36, tap, ks);
+    return *reinterpret_cast<const h8_t*>(wa + (((lin / 36) * 9 + tap) * 4 + ks) * 512);
+  };
+  h8_t fa[2][12];  // two groups of 12 fragments in flight
 #pragma unroll
-  for (int i = 0; i < 12; ++i) fa[0][i] = *reinterpret_cast<const h8_t*>(wa + i * 512);
+  for (int i = 0; i < 12; ++i) fa[0][i] = wfrag(i);
   __syncthreads();  // s_cell
 #pragma unroll
   for (int chunk = 0; chunk < 2; ++chunk) {  // unrolled: the fragment double buffer is indexed by the parity of g_lin
@@ -279,12 +289,13 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
       const int g_lin = chunk * 3 + grp;  // 0..5 over the whole k range; buffers alternate across the chunk boundary
       if (g_lin + 1 < 6) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) fa[(g_lin + 1) & 1][i] = *reinterpret_cast<const h8_t*>(wa + ((g_lin + 1) * 12 + i) * 512);
+        for (int i = 0; i < 12; ++i) fa[(g_lin + 1) & 1][i] = wfrag((g_lin + 1) * 12 + i);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
-        const int tap = grp * 3 + (i >> 2), ks = i & 3;
+        int tap, ks;
+        frag_of(grp * 12 + i, tap, ks);
         const h8_t b0 = *reinterpret_cast<const h8_t*>(s_p + j * kDsPatchLd + tap * 64 + ks * 16 + hh * 8);
         const h8_t b1 = *reinterpret_cast<const h8_t*>(s_p + (32 + j) * kDsPatchLd + tap * 64 + ks * 16 + hh * 8);
         acc[0] = mfma32(fa[g_lin & 1][i], b0, acc[0]);

@@ -355,9 +355,14 @@ __global__ __launch_bounds__(1024) void k_topk(TopkArgs a) {
   __shared__ int s_remaining, s_cnt, s_done;
   __shared__ unsigned long long s_out[1024];  // rank-sort output (K <= 1024)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int M = min(a.cand_count[b], a.cap);
+  const int n_cand = a.cand_count[b];
+  const int M = min(n_cand, a.cap);
   const int K = min(M, a.max_kp);
-  if (a.n_cand_out && tid == 0) a.n_cand_out[b] = a.cand_count[b];
+  if (a.reset_count) {  // every thread has its copy of the counter before it is cleared for the next call
+    __syncthreads();
+    if (tid == 0) a.reset_count[b] = 0;
+  }
+  if (a.n_cand_out && tid == 0) a.n_cand_out[b] = n_cand;
   if (tid == 0) a.n_out[b] = K;
   if (K == 0) return;
   const unsigned long long* cand = a.cand + (size_t)b * a.cap;

@@ -83,14 +83,20 @@ def test_strip_conv_kernel_agrees_with_ping_pong(weights_dir, tmp_path):
     _assert_same_features_fp16("strip", base, alt)
 
 
-def test_ct32_conv_kernel_agrees_with_the_64_row_tile_kernel(weights_dir, tmp_path):
-    """SUPERSLAM_HIP_CONV128=ct32: the 128-input-channel layers on the 32-row-tile kernel of conv_pp.hip (two 64-channel
-    chunks) instead of conv_pp128.hip (four 32-channel chunks, weight ring by LDS-DMA, buffer-addressed staging).  Same
-    operands, different k order (chunk size) in the fp32 accumulation: compared by the suite's fp16 tolerances.
+def test_ct32_conv_kernel_is_bit_identical_to_the_16_row_tile_kernel(weights_dir, tmp_path):
+    """The 128-input-channel layers have two kernels on the default path: conv_pp128.hip's 16 x 32-pixel tiles with 64-row cout
+    tiles (throughput batches) and conv_pp.hip's 8 x 32-pixel tiles with 32-row cout tiles (latency mode: a frame or two per call
+    would leave most CUs without a workgroup on the big tiles; sp_conv3x3_pp picks by tile count).  Both feed the same fp16 operands
+    into an fp32 accumulator that starts at the bias IN THE SAME ORDER (32-channel half, kx, k-step, ky), so they are bit-identical:
+    a frame extracted alone equals the same frame inside a batch.  SUPERSLAM_HIP_CONV128=th16 / ct32 force one or the other.
     The worker's 200 x 328 image gives those layers odd tile counts, partial edge tiles and a one-tile-per-group tail."""
-    base = _run({}, weights_dir, tmp_path, "default")
+    base = _run({"SUPERSLAM_HIP_CONV128": "th16"}, weights_dir, tmp_path, "th16")
     alt = _run({"SUPERSLAM_HIP_CONV128": "ct32"}, weights_dir, tmp_path, "ct32")
-    _assert_same_features_fp16("ct32", base, alt)
+    auto = _run({}, weights_dir, tmp_path, "auto")
+    for tag in ("l", "r"):
+        for other in (alt, auto):
+            np.testing.assert_array_equal(base["kp_" + tag], other["kp_" + tag])
+            np.testing.assert_array_equal(base["d_" + tag].view(np.uint16), other["d_" + tag].view(np.uint16))
 
 
 def test_streaming_convpb_agrees_with_the_implicit_gemm_template(weights_dir, tmp_path):
@@ -167,7 +173,9 @@ def test_conv_kernels_agree_on_tile_corner_cases(weights_dir, tmp_path):
     res = {}
     # th8: the 8-row-tile register-staged kernel the 128-channel layers ran on before the 16-row LDS-DMA kernel; dma64: the
     # LDS-DMA kernel also for the 64-channel layers (two resident chunks) - both opt-in A/B paths of conv_pp128.hip
+    # th16 / ct32: the two default-path kernels of the 128-input-channel layers, each forced for every shape (bit-identical to each other)
     variants = (("default", {}), ("strip", {"SUPERSLAM_HIP_CONV": "strip"}), ("ct32", {"SUPERSLAM_HIP_CONV128": "ct32"}),
+                ("th16", {"SUPERSLAM_HIP_CONV128": "th16"}),
                 ("th8", {"SUPERSLAM_HIP_CONV128": "th8"}), ("dma64", {"SUPERSLAM_HIP_CONV64": "dma"}))
     for name, env in variants:
         out = str(tmp_path / ("dense_" + name + ".npz"))
@@ -181,6 +189,9 @@ def test_conv_kernels_agree_on_tile_corner_cases(weights_dir, tmp_path):
             dd = np.abs(res["default"]["d_%dx%d" % (h, w)] - res[alt]["d_%dx%d" % (h, w)]).max()
             print(f"{h}x{w} default vs {alt}: logits max|d| {dl:.3e}, descriptor grid max|d| {dd:.3e}")
             assert dl < 4e-2 and dd < 1e-2, (h, w, alt, dl, dd)
+        for a in ("default", "ct32"):  # same accumulation order: exactly equal
+            np.testing.assert_array_equal(res["th16"]["l_%dx%d" % (h, w)], res[a]["l_%dx%d" % (h, w)])
+            np.testing.assert_array_equal(res["th16"]["d_%dx%d" % (h, w)], res[a]["d_%dx%d" % (h, w)])
 
 
 def test_mfma_probe_reports_a_plausible_rate():
