@@ -534,17 +534,35 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
 #ifndef SSHIP_FFN_ABL
 #define SSHIP_FFN_ABL 0
 #endif
+#ifndef SSHIP_FFN_DEEP_PFK
+#define SSHIP_FFN_DEEP_PFK 4  // k-steps of the fused projection requested before the residual phase (0, 4, 8; 16 for NEXT_MT <= 2)
+#endif
+#ifndef SSHIP_FFN_DEEP
+#define SSHIP_FFN_DEEP 1  // build.py --variant -DSSHIP_FFN_DEEP=0: the latency-mode kernel without the deep register prefetch (A/B)
+#endif
 // NT = 32-token N-tiles per workgroup.  Every weight fragment a wave streams from L2 feeds NT MFMAs; at NT = 2 the
 // three GEMMs need 64 B/clk/CU of L2 -> L1 bandwidth to keep the matrix pipe busy (= the TCP's peak, so the kernel
 // was bound by the weight stream: 1.18 MB per 64 tokens).  NT = 4 halves the stream per token (throughput batches);
 // NT = 2 keeps more workgroups in flight for a few pairs (latency mode).
 // PROJ: projection only (the first layer's Wqkv has no FFN in front of it): stage the tile, run the fused projection.
+// DEEP (NT = 1, latency mode: one 32-token tile per workgroup, one workgroup per CU, 38 CUs busy for one pair).  The launch is a serial
+// chain  ffn.0 stream -> LayerNorm -> GELU -> ffn.3 stream -> residual -> projection stream -> epilogue  in which the three weight
+// streams run at the L1's 64 B/clk (18 k clocks for 1.15 MB) and stand still during the VALU phases between them (13 k of a 29-34 k-clock
+// tile, profiles/r04_j_*).  Measured (profiles/r04_s_*): requesting ffn.3's whole fragment stream (32 KB = 128 VGPRs per wave) before the
+// LayerNorm statistics, or dealt out over the GELU loop four loads per step, only MOVES the time - the 8 x 32 one-KB loads occupy the
+// CU's address path for ~4 k clocks and the issuing waves with it (LayerNorm 3.3 -> 6.1 k / GELU 3.7 -> 5.8 k, ffn.3 4.3 -> 2.1 k).
+// What is free is small: the first SSHIP_FFN_DEEP_PFK k-steps of the projection requested before the residual phase, whose waits
+// (barrier, residual operand) are not address-path time (tail MFMA 5.1 -> 4.25 k / 9.3 -> 7.6 k, residual unchanged), and barriers
+// that wait for LDS traffic only (__syncthreads() drains vmcnt too and would stall every wave on its own prefetch).
+__device__ __forceinline__ void ffn_bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NEXT_MT, bool HEADS, int NT, bool PROJ>
 __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                 const float* __restrict__ b0, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const _Float16* __restrict__ w3p,
                                                 const float* __restrict__ b3, _Float16* __restrict__ x, FfnTail tail) {
   constexpr int NTOK = NT * 32;
+  constexpr bool DEEP = NT == 1 && !PROJ && SSHIP_FFN_DEEP;
+  auto barrier = [&]() __attribute__((always_inline)) { if constexpr (DEEP) ffn_bar_lds(); else __syncthreads(); };
   // ffn.0 k-steps per register-prefetch group.  Two groups are in flight: 4 k-steps x 2 M-tiles x 2 groups = 16 one-KB loads per wave.
   // Round 4 (scripts/ubench/l2_stream.hip, profiles/r04_h_*): a CU streams an L2-resident weight set at 123-132 GB/s with 8 waves and
   // 8-16 loads in flight per wave, and at 56-62 GB/s with 32 - the rate HALVES past 16 per wave.  Groups of 8 k-steps (32 in flight)
@@ -632,6 +650,8 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     if (tail.trace && it == tail.trace_it && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
   };
   stamp(0);
+  constexpr int PFK = !DEEP || NEXT_MT == 0 ? 0 : SSHIP_FFN_DEEP_PFK;  // DEEP: k-steps of the fused projection prefetched into atp
+  h8_t atp[PFK > 0 ? PFK : 1][NEXT_MT > 0 ? NEXT_MT : 1];
   if constexpr (!PROJ) {
   // ---- ffn.0 : rows [64 wave, +64) x NTOK tokens, K = 512 ----
   f16x_t acc[2][NT];
@@ -703,7 +723,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     sq += __shfl_xor(sq, 32, 64);
     if (hh == 0) { s_red[wave][n * 32 + j] = sum[n]; s_red[8 + wave][n * 32 + j] = sq; }
   }
-  __syncthreads();
+  barrier();
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     float t = 0.f, q = 0.f;
@@ -743,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
       }
     }
   stamp(3);
-  __syncthreads();
+  barrier();
   stamp(4);
   // ---- ffn.3 : rows [32 wave, +32) x NTOK tokens, K = 512, + residual ----
   f16x_t ac2[NT];
@@ -777,8 +797,17 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
     }
   }
   stamp(5);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed (before the barrier below / the next tile's first barrier)
-  if constexpr (NEXT_MT > 0) __syncthreads();  // all waves are done reading the hidden tile: s_x gets the new x
+  if (!DEEP || has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed (before the barrier below / the next tile's first barrier)
+  // DEEP: the first PFK k-steps of the fused projection, requested before the residual phase (the ffn.3 fragments are dead now)
+  if constexpr (PFK > 0) {
+    const _Float16* wpp = pj.wpack + (size_t)wave * (16 * NEXT_MT * 512) + lane * 8;
+#pragma unroll
+    for (int i = 0; i < PFK; ++i)
+#pragma unroll
+      for (int m = 0; m < NEXT_MT; ++m) atp[i][m] = *reinterpret_cast<const h8_t*>(wpp + (i * NEXT_MT + m) * 512);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (NEXT_MT > 0) barrier();  // all waves are done reading the hidden tile: s_x gets the new x
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int c = wave * 32 + hh * 4 + g * 8;
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   stamp(6);
   }  // !PROJ
   if constexpr (NEXT_MT > 0) {
-    __syncthreads();
+    barrier();
     stamp(7);
     // ---- fused next projection: rows [NEXT_MT*32*wave, +NEXT_MT*32) x NTOK tokens, K = 256 ----
     f16x_t ac3[NEXT_MT][NT];
@@ -840,38 +869,47 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
 #pragma unroll
           for (int g = 0; g < 4; ++g) bqk[m][g] = *reinterpret_cast<const float4*>(pj.bias + (m * 8 + wave) * 32 + hh * 4 + g * 8);
       }
+      constexpr int NG = (16 - PFK) / GT;  // streamed groups behind the PFK prefetched k-steps (DEEP; PFK = 0 otherwise)
       h8_t at[2][GT][NEXT_MT];
+      if constexpr (NG > 0) {
 #pragma unroll
-      for (int i = 0; i < GT; ++i)
+        for (int i = 0; i < GT; ++i)
 #pragma unroll
-        for (int m = 0; m < NEXT_MT; ++m) at[0][i][m] = *reinterpret_cast<const h8_t*>(wp + (i * NEXT_MT + m) * 512);
+          for (int m = 0; m < NEXT_MT; ++m) at[0][i][m] = *reinterpret_cast<const h8_t*>(wp + ((PFK + i) * NEXT_MT + m) * 512);
+      }
+      auto kstep = [&](int ks, const h8_t (&a)[NEXT_MT]) __attribute__((always_inline)) {
+        h8_t bf[NT];
 #pragma unroll
-      for (int grp = 0; grp < 16 / GT; ++grp) {
+        for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + ks * 16);
+#pragma unroll
+        for (int m = 0; m < NEXT_MT; ++m) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if ((VMASK >> m) & 1) ac3[m][n] = mfma32(bf[n], a[m], ac3[m][n]);
+            else ac3[m][n] = mfma32(a[m], bf[n], ac3[m][n]);
+          }
+        }
+      };
+      if constexpr (PFK > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(SSHIP_FFN_ABL & 8)) {
+#pragma unroll
+          for (int i = 0; i < PFK; ++i) kstep(i, atp[i]);
+        }
+      }
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
         if (SSHIP_FFN_ABL & 8) break;
-        if (grp + 1 < 16 / GT) {
+        if (grp + 1 < NG) {
 #pragma unroll
           for (int i = 0; i < GT; ++i)
 #pragma unroll
             for (int m = 0; m < NEXT_MT; ++m)
-              at[(grp + 1) & 1][i][m] = *reinterpret_cast<const h8_t*>(wp + (((grp + 1) * GT + i) * NEXT_MT + m) * 512);
+              at[(grp + 1) & 1][i][m] = *reinterpret_cast<const h8_t*>(wp + ((PFK + (grp + 1) * GT + i) * NEXT_MT + m) * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < GT; ++i) {
-          const int ks = grp * GT + i;
-          h8_t bf[NT];
-#pragma unroll
-          for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const h8_t*>(bfp + n * 32 * kFfnLd + ks * 16);
-#pragma unroll
-          for (int m = 0; m < NEXT_MT; ++m) {
-            const h8_t a = at[grp & 1][i][m];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              if ((VMASK >> m) & 1) ac3[m][n] = mfma32(bf[n], a, ac3[m][n]);
-              else ac3[m][n] = mfma32(a, bf[n], ac3[m][n]);
-            }
-          }
-        }
+        for (int i = 0; i < GT; ++i) kstep(PFK + grp * GT + i, at[grp & 1][i]);
       }
       stamp(8);
       if (PROJ && NT <= 2 && has_next) stage_tile(tile + nwg, s_xn, wave, lane);  // the epilogue covers the DMA
@@ -1027,6 +1065,20 @@ static hipError_t launch_ffn(int nt, int tokens, int extra_wg, hipStream_t s, A.
 #ifndef SSHIP_FFN4_BSTORE
 #define SSHIP_FFN4_BSTORE 5
 #endif
+// Energy ablations of the throughput kernel (build.py --variant ... -DSSHIP_FFN4_ABL=n, scripts/dev/run_energy_abl.sh: rocm-smi power x launch
+// time per variant): 1 no MFMAs (operands still delivered), 2 no LayerNorm / GELU math, 4 every weight fragment read from offset 0 (the
+// loads of a phase collapse into one: no L2 -> register stream), 8 no projection epilogue (rotary, conversion, stores).  Results are wrong by design.
+#ifndef SSHIP_FFN4_ABL
+#define SSHIP_FFN4_ABL 0
+#endif
+__device__ __forceinline__ f16x_t mfma32_abl(h8_t a, h8_t b, f16x_t c) {
+  if constexpr ((SSHIP_FFN4_ABL & 1) != 0) {
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+  } else {
+    return mfma32(a, b, c);
+  }
+}
 template <int NEXT_MT, bool HEADS, bool PROJ>
 __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__ ctx, const _Float16* __restrict__ w0p,
                                                     const float* __restrict__ b0, const float* __restrict__ gamma,
@@ -1097,7 +1149,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, (int)0x7ffffff0, 0x00020000);
   };
   auto wload = [&](__amdgpu_buffer_rsrc_t r, int halfs) __attribute__((always_inline)) {  // fragment at base + halfs (+ lane * 8)
-    return __builtin_bit_cast(h8_t, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, halfs * 2 + zero, 0));
+    return __builtin_bit_cast(h8_t, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, ((SSHIP_FFN4_ABL & 4) ? 0 : halfs * 2) + zero, 0));
   };
   // the epilogue's 16-byte stores the same way: lane offset in one VGPR, everything else scalar (q / k / V^T tiles are in fragment
   // order, lane * 16 B again; x rows: token j -> j * 512 B + 16 hh)
@@ -1156,7 +1208,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[f][n] = mfma32(ab[ks % R0][f], bf[ks & 1][n], acc[f][n]);
+        for (int n = 0; n < NT; ++n) acc[f][n] = mfma32_abl(ab[ks % R0][f], bf[ks & 1][n], acc[f][n]);
     }
   }
   stamp(1);
@@ -1213,8 +1265,8 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const f2_t a01 = {acc[f][n][4 * g + 0], acc[f][n][4 * g + 1]}, a23 = {acc[f][n][4 * g + 2], acc[f][n][4 * g + 3]};
-        const f2_t o01 = gelu2((a01 * rstd[n] + mean[n]) * g01 + b01);
-        const f2_t o23 = gelu2((a23 * rstd[n] + mean[n]) * g23 + b23);
+        const f2_t o01 = (SSHIP_FFN4_ABL & 2) ? a01 : gelu2((a01 * rstd[n] + mean[n]) * g01 + b01);
+        const f2_t o23 = (SSHIP_FFN4_ABL & 2) ? a23 : gelu2((a23 * rstd[n] + mean[n]) * g23 + b23);
         *reinterpret_cast<h4_t*>(s_x + (n * 32 + j) * kFfnLd + c) = to_h4(o01[0], o01[1], o23[0], o23[1]);
       }
     }
@@ -1255,7 +1307,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) ac2[m][n] = mfma32(a3[ks % R3][m], bf[ks & 1][n], ac2[m][n]);
+        for (int n = 0; n < NT; ++n) ac2[m][n] = mfma32_abl(a3[ks % R3][m], bf[ks & 1][n], ac2[m][n]);
     }
   }
   stamp(5);
@@ -1347,13 +1399,20 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
           const h8_t a = at[ks % RT][m];
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            if ((VMASK >> m) & 1) ac3[m][n] = mfma32(bf[ks & 1][n], a, ac3[m][n]);
-            else ac3[m][n] = mfma32(a, bf[ks & 1][n], ac3[m][n]);
+            if ((VMASK >> m) & 1) ac3[m][n] = mfma32_abl(bf[ks & 1][n], a, ac3[m][n]);
+            else ac3[m][n] = mfma32_abl(a, bf[ks & 1][n], ac3[m][n]);
           }
         }
       }
       stamp(8 + pass);
-      if constexpr (HEADS) {
+      if constexpr (SSHIP_FFN4_ABL & 8) {
+        float keep = 0.f;
+#pragma unroll
+        for (int m = 0; m < NEXT_MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) keep += ac3[m][n][0];
+        if (keep == 1.2345e-30f) tail.trace[0] = 1;  // the accumulators stay live; never true
+      } else if constexpr (HEADS) {
 #pragma unroll
         for (int m = 0; m < NEXT_MT; ++m) {
           const int R0 = (m * 8 + cb) * 32;  // first output row of this M-tile
