@@ -516,7 +516,7 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
               B * (K * 9 * 128 * 2 + K * 256 * 2 + 8 * K), "9 x 256 B encoder rows per keypoint read + [N,256] fp16 written + 8N index bytes, "
               "per image (SURVEY 8(d) gather figure is the last two terms: N*256*2 read + write + 8N)")
     ms_as = lg_stage(6) + lg_stage(7)
-    hbm_entry("k_assign_stream x2 + combine (log-sum-exp pass, arg-max pass; no sim matrix in memory)", ms_as,
+    hbm_entry("k_assign_stream x2 + mutual filter (log-sum-exp pass, arg-max pass; no sim matrix in memory)", ms_as,
               P * (2 * 2 * n * 256 * 2 + 4 * n * 4),
               "final projections of both images [n,256] fp16 read once per pass + match vectors, per pair (matrix-pipe / VALU bound)",
               P * 2 * ((n + 31) // 32 + 4) * n * 256 * 2)

@@ -1774,6 +1774,7 @@ __global__ __launch_bounds__(64 * kColRG) void k_assign_col_arg(const float* __r
   }
 }
 // filter_matches(scores, 0.1): mutual check, mscores0 = mutual ? exp(max0) : 0, matches0 = valid ? m0 : -1.
+// (legacy path: the arg-max rows / columns and scores are in ws)
 __global__ void k_assign_final(const int* __restrict__ lens, int NP, const float* __restrict__ ws, int max_kp,
                                float thr, int32_t* __restrict__ matches0, float* __restrict__ mscores0) {
   const int pair = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1800,7 +1801,7 @@ __global__ void k_assign_final(const int* __restrict__ lens, int NP, const float
 // A wave owns a 32-row tile of image 0, keeps its md0 fragments in registers and walks the column tiles of image 1
 // (fragments streamed through a two-halves register ring).  PASS 0: online log-sum-exp per row (complete in the wave) and
 // per (row tile, column) partials; PASS 1: row arg-max of S_ij (complete) and per (row tile, column) partial arg-max.
-// k_assign_combine folds the NP / 32 column partials.  The fp32 [pairs][NP][NP] matrix (92 MB at 64 pairs, written once and
+// PASS 1 folds PASS 0's partials in its prologue, k_assign_mutual those of PASS 1.  The fp32 [pairs][NP][NP] matrix (92 MB at 64 pairs, written once and
 // read four times: 0.22 ms) is never materialised; sship_lg_debug_read(SIM) computes it on demand with k_lg_sim.
 //   S_ij = (sim - lse_row_i) + (sim - lse_col_j) + ls0_i + ls1_j = 2 sim + c_i + d_j ; first index wins ties (torch.max).
 // The arg-max over j needs only 2 sim + d_j (c_i is added to the winner afterwards), the one over i only 2 sim + c_i:
@@ -1818,16 +1819,35 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
 // kAssignCh column chunks per row tile (blockIdx.z): 4x the waves (a wave per row tile alone leaves ~1 wave per SIMD with every
 // dependent-instruction stall exposed: 90 us per pass), at the price of per-chunk row partials next to the per-tile column ones
 constexpr int kAssignCh = 4;
+// folds of the per-tile / per-chunk partials (ascending part index: one fixed summation order whoever folds them).  PASS 1 of
+// k_assign_stream folds the log-sum-exp partials of PASS 0 in its prologue and k_assign_mutual the arg-max partials of PASS 1 -
+// the two k_assign_combine launches this replaced were 7 us each in a one-pair call (5 workgroups, two dependent round trips).
+__device__ __forceinline__ float fold_lse(const float2* p, int nparts, int NP) {
+  float m = -INFINITY, s = 0.f;
+  for (int k = 0; k < nparts; ++k) { const float2 v = p[(size_t)k * NP]; lse_merge(m, s, v.x, v.y); }
+  return m + logf(s);
+}
+__device__ __forceinline__ void fold_argmax(const float2* p, int nparts, int NP, float& best, int& bi) {  // ties: smaller index
+  best = -INFINITY; bi = 0x7fffffff;
+  for (int k = 0; k < nparts; ++k) {
+    const float2 v = p[(size_t)k * NP];
+    const int i = __float_as_int(v.y);
+    if (v.x > best || (v.x == best && i < bi)) { best = v.x; bi = i; }
+  }
+}
+// pcol / prow: the partials this pass WRITES; pcol_in / prow_in (PASS 1): the log-sum-exp partials PASS 0 wrote (different buffers:
+// a workgroup of PASS 1 that finishes early must not overwrite partials a later one still folds)
 template <int PASS>
 __global__ __launch_bounds__(256, 2) void k_assign_stream(const _Float16* __restrict__ md, const float* __restrict__ logsig,
-                                                       const int* __restrict__ lens, int NP, float* __restrict__ ws,
-                                                       float* __restrict__ pcol, float* __restrict__ prow) {
+                                                       const int* __restrict__ lens, int NP, float* __restrict__ pcol,
+                                                       float* __restrict__ prow, const float* __restrict__ pcol_in,
+                                                       const float* __restrict__ prow_in) {
   constexpr int kChunkCols = (kMaxKp / 32 + kAssignCh - 1) / kAssignCh * 32;  // columns of one chunk at most
   __shared__ __attribute__((aligned(16))) float s_lc[PASS ? kChunkCols : 4];  // d_j = ls1_j - lse_col_j of this chunk's columns
+  __shared__ float s_lr[PASS ? 128 : 4];                                       // lse_row of the workgroup's 128 rows
   const int pair = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jl = lane & 31, hh = lane >> 5;
   const int NT = NP >> 5, ti = blockIdx.x * 4 + wave, i0 = ti * 32;
   const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
-  float* w = ws + (size_t)pair * 5 * NP;
   if ((int)blockIdx.x * 128 >= n0) return;     // no row of this workgroup exists (uniform: before any further barrier)
   const bool active = ti < NT && i0 < n0;      // wave-uniform: a wave past the end still stages column tiles and joins the barriers
   const _Float16* A = md + ((size_t)(2 * pair) * NP + min(i0 + jl, NP - 1)) * 256 + hh * 8;
@@ -1839,14 +1859,6 @@ __global__ __launch_bounds__(256, 2) void k_assign_stream(const _Float16* __rest
   const int ro = 4 * hh;  // register r of this lane <-> tile-local index (r & 3) + 8 (r >> 2) + ro
   // PASS 1 inputs: lse_row / ls0 of the lane's own row, and of the 16 rows its acc_j registers stand for
   float c_i = 0.f, c_r[PASS ? 16 : 1];  // c = ls0 - lse_row
-  if constexpr (PASS == 1) {
-    c_i = logsig[(size_t)(2 * pair) * NP + min(my_i, NP - 1)] - w[min(my_i, NP - 1)];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = min(i0 + (r & 3) + 8 * (r >> 2) + ro, NP - 1);
-      c_r[r] = logsig[(size_t)(2 * pair) * NP + i] - w[i];
-    }
-  }
   float rm = -INFINITY, rs = 0.f;  // PASS 0: running (max, sum) of the lane's row;  PASS 1: running best value (rm) ...
   int rj = 0x7fffffff;             // ... and its column
   const int ntj_all = (n1 + 31) >> 5, per = (ntj_all + kAssignCh - 1) / kAssignCh;
@@ -1854,8 +1866,25 @@ __global__ __launch_bounds__(256, 2) void k_assign_stream(const _Float16* __rest
   if (tj_lo >= ntj) return;
   const int jc0 = tj_lo * 32;  // first column of this chunk: s_lc / s_l1 are indexed by j - jc0
   if constexpr (PASS == 1) {
-    for (int j = threadIdx.x; j < (ntj - tj_lo) * 32; j += 256)
-      s_lc[j] = logsig[(size_t)(2 * pair + 1) * NP + jc0 + j] - w[NP + jc0 + j];  // d_j = ls1_j - lse_col_j
+    // PASS 0's partials -> lse_row of this workgroup's rows (over the column chunks that got tiles), lse_col of this chunk's columns
+    // (over the row tiles that exist); rows >= n0 / columns >= n1 are masked further down and get a finite dummy
+    const int nch = (ntj_all + per - 1) / max(per, 1), nrt = (n0 + 31) >> 5;
+    if (threadIdx.x < 128) {
+      const int i = blockIdx.x * 128 + threadIdx.x;
+      s_lr[threadIdx.x] = i < n0 ? fold_lse(reinterpret_cast<const float2*>(prow_in) + (size_t)pair * kAssignCh * NP + i, nch, NP) : 0.f;
+    }
+    for (int j = threadIdx.x; j < (ntj - tj_lo) * 32; j += 256) {
+      const int jj = jc0 + j;
+      s_lc[j] = jj < n1 ? logsig[(size_t)(2 * pair + 1) * NP + jj] - fold_lse(reinterpret_cast<const float2*>(pcol_in) + (size_t)pair * NT * NP + jj, nrt, NP)
+                        : 0.f;  // d_j = ls1_j - lse_col_j
+    }
+    __syncthreads();
+    c_i = logsig[(size_t)(2 * pair) * NP + min(my_i, NP - 1)] - s_lr[wave * 32 + jl];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int il = (r & 3) + 8 * (r >> 2) + ro;
+      c_r[r] = logsig[(size_t)(2 * pair) * NP + min(i0 + il, NP - 1)] - s_lr[wave * 32 + il];
+    }
   }
   // The four waves of the workgroup walk the same column tiles: a tile (32 rows x 512 B of image 1) is fetched ONCE, with
   // coalesced loads (32 lanes = one row), into a padded LDS buffer (row stride 528 B: conflict-free ds_read_b128 fragments)
@@ -1982,37 +2011,34 @@ __global__ __launch_bounds__(256, 2) void k_assign_stream(const _Float16* __rest
     if (hh == 0 && my_i < n0) *pr = make_float2(rm + c_i, __int_as_float(rj));
   }
 }
-// folds the partials: columns over the row tiles, rows over the column chunks.  PASS 0 -> lse_col / lse_row, PASS 1 -> arg-max
-// row of every column / arg-max column (and its score) of every row; ties: smaller index
-template <int PASS>
-__global__ __launch_bounds__(256) void k_assign_combine(const float* __restrict__ pcol, const float* __restrict__ prow,
-                                                        const int* __restrict__ lens, int NP, float* __restrict__ ws) {
-  const int pair = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;  // t < NP: column t, NP <= t < 2 NP: row t - NP
+// filter_matches(scores, 0.1) on the partials of PASS 1: row i's arg-max column j and score (folded over the column chunks), column
+// j's arg-max row (folded over the row tiles), mutual check, mscores0 = mutual ? exp(max0) : 0, matches0 = valid ? j : -1.
+// A row / column of NaN / -inf scores keeps index 0, like torch.max on a degenerate row (never an out-of-range index).
+__global__ __launch_bounds__(256) void k_assign_mutual(const float* __restrict__ pcol, const float* __restrict__ prow,
+                                                       const int* __restrict__ lens, int NP, int max_kp, float thr,
+                                                       int32_t* __restrict__ matches0, float* __restrict__ mscores0) {
+  const int pair = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_kp) return;
   const int n0 = min(max(lens[2 * pair], 0), NP), n1 = min(max(lens[2 * pair + 1], 0), NP);
   const int NT = NP >> 5;
-  float* w = ws + (size_t)pair * 5 * NP;
-  const bool is_col = t < NP;
-  const int idx = is_col ? t : t - NP;
-  if (idx >= (is_col ? n1 : n0)) return;
-  const int ntj_all = (n1 + 31) >> 5, per = (ntj_all + kAssignCh - 1) / kAssignCh;
-  const int nparts = is_col ? (n0 + 31) >> 5 : (ntj_all + per - 1) / max(per, 1);  // row tiles that exist / chunks that got column tiles
-  const float2* p = reinterpret_cast<const float2*>(is_col ? pcol : prow) + (size_t)pair * (is_col ? NT : kAssignCh) * NP + idx;
-  if constexpr (PASS == 0) {
-    float m = -INFINITY, s = 0.f;
-    for (int k = 0; k < nparts; ++k) { const float2 v = p[(size_t)k * NP]; lse_merge(m, s, v.x, v.y); }
-    w[(is_col ? NP : 0) + idx] = m + logf(s);
-  } else {
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int k = 0; k < nparts; ++k) {
-      const float2 v = p[(size_t)k * NP];
-      const int i = __float_as_int(v.y);
-      if (v.x > best || (v.x == best && i < bi)) { best = v.x; bi = i; }
+  int mj = -1;
+  float ms = 0.f;
+  if (i < n0 && n1 > 0) {
+    const int ntj_all = (n1 + 31) >> 5, per = (ntj_all + kAssignCh - 1) / kAssignCh;
+    float best, cbest;
+    int j, ci;
+    fold_argmax(reinterpret_cast<const float2*>(prow) + (size_t)pair * kAssignCh * NP + i, (ntj_all + per - 1) / max(per, 1), NP, best, j);
+    if (j == 0x7fffffff) j = 0;
+    bool mutual = false;
+    if ((unsigned)j < (unsigned)n1) {
+      fold_argmax(reinterpret_cast<const float2*>(pcol) + (size_t)pair * NT * NP + j, (n0 + 31) >> 5, NP, cbest, ci);
+      mutual = (ci == 0x7fffffff ? 0 : ci) == i;
     }
-    // a row / column of NaN / -inf scores keeps index 0, like torch.max on a degenerate row (never an out-of-range index)
-    if (is_col) reinterpret_cast<int*>(w)[4 * NP + idx] = bi == 0x7fffffff ? 0 : bi;
-    else { w[2 * NP + idx] = best; reinterpret_cast<int*>(w)[3 * NP + idx] = bi == 0x7fffffff ? 0 : bi; }
+    ms = mutual ? expf(best) : 0.f;
+    mj = (mutual && ms > thr) ? j : -1;
   }
+  matches0[(size_t)pair * max_kp + i] = mj;
+  mscores0[(size_t)pair * max_kp + i] = ms;
 }
 
 // stage = 0: both passes + the mutual filter (a match call); 1 / 2: one pass only (sship_lg_bench_stage)
@@ -2028,15 +2054,17 @@ void launch_lg_assign(const _Float16* md, const float* logsig, const int* lens, 
     hipLaunchKernelGGL(k_assign_row_arg, dim3(d.NP / 4, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
     hipLaunchKernelGGL(k_assign_col_arg, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, logsig, lens, d.NP, ws);
   } else {
-    float* prow = pcol + (size_t)P * NT * d.NP * 2;  // [P][kAssignCh][NP][2] behind the column partials [P][NT][NP][2]
-    if (stage == 0 || stage == 1) {
-      hipLaunchKernelGGL(k_assign_stream<0>, dim3((NT + 3) / 4, P, kAssignCh), dim3(256), 0, s, md, logsig, lens, d.NP, ws, pcol, prow);
-      hipLaunchKernelGGL(k_assign_combine<0>, dim3((2 * d.NP + 255) / 256, P), dim3(256), 0, s, pcol, prow, lens, d.NP, ws);
-    }
-    if (stage == 0 || stage == 2) {
-      hipLaunchKernelGGL(k_assign_stream<1>, dim3((NT + 3) / 4, P, kAssignCh), dim3(256), 0, s, md, logsig, lens, d.NP, ws, pcol, prow);
-      hipLaunchKernelGGL(k_assign_combine<1>, dim3((2 * d.NP + 255) / 256, P), dim3(256), 0, s, pcol, prow, lens, d.NP, ws);
-    }
+    // partials inside pcol's allocation (P * NP * NP floats): [P][NT][NP][2] column + [P][kAssignCh][NP][2] row partials of PASS 0, then those of PASS 1
+    float* prow = pcol + (size_t)P * NT * d.NP * 2;
+    float* pcol1 = prow + (size_t)P * kAssignCh * d.NP * 2;
+    float* prow1 = pcol1 + (size_t)P * NT * d.NP * 2;
+    if (stage == 0 || stage == 1)
+      hipLaunchKernelGGL(k_assign_stream<0>, dim3((NT + 3) / 4, P, kAssignCh), dim3(256), 0, s, md, logsig, lens, d.NP, pcol, prow, nullptr, nullptr);
+    if (stage == 0 || stage == 2)
+      hipLaunchKernelGGL(k_assign_stream<1>, dim3((NT + 3) / 4, P, kAssignCh), dim3(256), 0, s, md, logsig, lens, d.NP, pcol1, prow1, pcol, prow);
+    if (stage == 0)
+      hipLaunchKernelGGL(k_assign_mutual, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, pcol1, prow1, lens, d.NP, max_kp, thr, matches0, mscores0);
+    return;
   }
   if (stage == 0)
     hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr,
