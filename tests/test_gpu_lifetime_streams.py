@@ -292,3 +292,43 @@ def test_closing_a_handle_with_an_uncollected_submission_and_reupload_of_a_pendi
     with pytest.raises(IndexError):
         sp.ring_host(5, 0)
     sp.close()
+
+
+def test_candidate_counters_survive_stage_benchmarks_and_batch_changes(weights_dir):
+    """k_topk clears the per-image candidate counters it has read, so an extraction needs no memset launch - unless the counters are
+    not known to be zero: a regrown buffer, a smaller batch after a larger one, or sship_sp_bench_layer's NMS stage, which leaves its
+    counts behind for the top-k stage.  Every sequence below must reproduce the first extraction bit for bit (a stale counter would
+    append the new candidates behind the old ones and change the selection)."""
+    import ctypes as C
+
+    from superslam_amd import SuperPoint, _lib
+    from superslam_amd.synth import make_stereo_pair
+
+    h, w = 200, 328
+    sp = SuperPoint(weights_dir["sp_path"], 300, 0.005, 4, max_batch=4)
+    assert sp.initialize(), sp.last_error
+    l, r = make_stereo_pair(h, w, 5)
+    l2, r2 = make_stereo_pair(h, w, 6)
+
+    def feats():
+        fl, fr = sp.extract_stereo(l, r)
+        return fl.keypoints.copy(), fr.keypoints.copy()
+
+    ref = feats()
+    for _ in range(2):                                     # back to back: the counters were cleared by the previous call's top-k
+        got = feats()
+        np.testing.assert_array_equal(ref[0], got[0]); np.testing.assert_array_equal(ref[1], got[1])
+    imgs = torch.from_numpy(np.stack([l2, r2, l, r])).cuda()
+    _lib.lib().sship_set_profiling(1)                      # keeps a copy of the input for the stage benchmarks
+    sp.extract_batch_device(imgs)                          # larger batch: buffers regrown, four counters in play
+    torch.cuda.synchronize()
+    _lib.lib().sship_set_profiling(0)
+    got = feats()                                          # smaller batch after the larger one
+    np.testing.assert_array_equal(ref[0], got[0]); np.testing.assert_array_equal(ref[1], got[1])
+    sp.extract_batch_device(imgs); torch.cuda.synchronize()
+    ms = C.c_float(0)
+    for layer in (12, 13):                                 # NMS stage (leaves counts behind), top-k stage (reads them, does not clear)
+        _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, layer, 4, h, w, 3, C.byref(ms), None))
+    got = feats()
+    np.testing.assert_array_equal(ref[0], got[0]); np.testing.assert_array_equal(ref[1], got[1])
+    sp.close()
