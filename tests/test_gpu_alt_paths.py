@@ -143,6 +143,33 @@ def test_two_stream_lightglue_is_bit_identical_to_one_stream(weights_dir, tmp_pa
     print("two-stream LightGlue: 64 pairs,", int((outs[0]["m"] >= 0).sum()), "matches, identical")
 
 
+def test_ffn_kernel_variants_agree(weights_dir, tmp_path, parity_report):
+    """The fused FFN block has four kernels: k_lg_ffn4 (throughput batches, default at 64 pairs), the 8-wave k_lg_ffn with 64-token tiles
+    (SUPERSLAM_HIP_FFN=8), the same kernel in its latency-mode instantiation (32-token tiles, prefetched projection, LDS-only barriers;
+    SUPERSLAM_HIP_FFN_NT=1 forces it onto a 64-pair batch, where every workgroup walks ~9 tiles: the multi-tile path one pair never takes)
+    and the 16-wave k_lg_ffn16 (SUPERSLAM_HIP_FFN=16, A/B).  Same operands, same k order per accumulator, fp32 LayerNorm / GELU: compared
+    with the default by the path-vs-path bar on ragged sequence lengths; the printout says which variants are bit-identical."""
+    import _lgcmp
+
+    res = {}
+    for name, env in (("ffn4", {}), ("ffn8", {"SUPERSLAM_HIP_FFN": "8"}), ("ffn8_nt1", {"SUPERSLAM_HIP_FFN": "8", "SUPERSLAM_HIP_FFN_NT": "1"}),
+                      ("ffn16", {"SUPERSLAM_HIP_FFN": "16"}), ("noprefetch", {"SUPERSLAM_HIP_LG_PREFETCH": "0"})):
+        out = str(tmp_path / ("ffn_" + name + ".npz"))
+        code = _LG_WORKER.format(root=ROOT, lg_path=weights_dir["lg_path"], out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = np.load(out)
+    for name in ("ffn8", "ffn8_nt1", "ffn16", "noprefetch"):
+        c = _lgcmp.compare(res[name]["m"].ravel(), res[name]["s"].ravel(), res["ffn4"]["m"].ravel(), res["ffn4"]["s"].ravel(), _lgcmp.PATH_VS_PATH_BAR)
+        same = bool(np.array_equal(res[name]["m"], res["ffn4"]["m"]) and np.array_equal(res[name]["s"], res["ffn4"]["s"]))
+        print(f"FFN variant {name} vs ffn4: identical {same}, agreement {c['agreement']:.5f}, mscores max|d| {c['mscores_maxd']:.2e}, flips {c['mutual_flips']}")
+        _lgcmp.check(c)
+        entry = parity_report.setdefault("lg_ffn_kernel_variants", {"pairs": 64, "reference": "k_lg_ffn4"})
+        # the default-path pair (ffn4 for batches, the 8-wave kernel for a few pairs) carries the enforced margin; the A/B kernel is recorded only
+        entry["mscores_maxd" if name == "ffn8" else name + "_maxd"] = c["mscores_maxd"]
+        entry[name + "_agreement"] = c["agreement"]
+
+
 _DENSE_WORKER = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, {root!r})
