@@ -104,7 +104,10 @@ extern "C" int sship_comm_create(const void* id_128, int rank, int world, sship_
 
 extern "C" void sship_comm_destroy(sship_comm* c) {
   if (!c) return;
-  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->comm && rccl().ok) {
+    (void)hipSetDevice(c->device);  // the calling thread may be bound elsewhere (handles are used from more than one thread)
+    (void)rccl().CommDestroy(c->comm);
+  }
   delete c;
 }
 extern "C" int sship_comm_rank(const sship_comm* c) { return c ? c->rank : -1; }
@@ -119,6 +122,7 @@ extern "C" int sship_gather_features_rccl(sship_comm* c, const void* desc_local_
   if (!desc_local_dev || !kp_local_dev || !n_local_dev || !desc_all_dev || !kp_all_dev || !n_all_dev)
     return fail(SSHIP_ERR_INVALID, "gather_features_rccl: null buffer");
   Rccl& r = rccl();
+  if (hipSetDevice(c->device) != hipSuccess) return fail(SSHIP_ERR_NO_DEVICE, "gather_features_rccl: cannot bind the communicator's device");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t u = (size_t)units_per_rank, k = (size_t)max_keypoints;
   // one grouped step: RCCL fuses the three all-gathers into a single launch / a single pass over the xGMI links
