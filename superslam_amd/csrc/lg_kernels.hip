@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   const float* mwq = tail.match_w + zero;
   const _Float16* bfp = s_x + j * kFfnLd + hh * 8;  // B fragment of N-tile n, k-step ks: bfp + n*32*kFfnLd + ks*16
   auto stamp = [&](int slot) {
-    if (tail.trace && it == 1 && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
+    if (tail.trace && it == tail.trace_it && lane == 0) tail.trace[((size_t)blockIdx.x * 8 + wave) * 12 + slot] = __builtin_readcyclecounter();
   };
   // Weight fragments are fetched with buffer loads: one lane-offset VGPR (lane * 16 B) for every load of the kernel, the
   // fragment's position as a scalar offset.  With flat 64-bit pointers hipcc spent ~230 VALU instructions per tile on address
@@ -1548,7 +1548,7 @@ static void ffn4_trace_report(unsigned long long* dev, int nwg, int next_mt, hip
   double sum[11] = {0}; long cnt = 0;
   for (int w = 0; w < nwg * 8; ++w) {
     const unsigned long long* t = h.data() + (size_t)w * 12;
-    if (!t[0] || !t[11]) continue;
+    if (t[0] < 1000000ull || !t[11]) continue;
     for (int i = 0; i < 11; ++i) {
       unsigned long long a = t[i], b = t[i + 1];
       if (!b) b = a;  // phases a variant does not have
