@@ -44,7 +44,7 @@
 #ifndef SSHIP_PP_NBUF
 #define SSHIP_PP_NBUF 3
 #endif
-// timing ablation (results are wrong): 1 = the MFMA loop reads its first fragments only and reuses them
+// timing / energy ablation (results are wrong): 1 = the MFMA loop reads its first fragments only and reuses them, 2 = no MFMAs (fragments still read)
 #ifndef SSHIP_PP_ABL
 #define SSHIP_PP_ABL 0
 #endif
@@ -378,7 +378,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
 #pragma unroll
       for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(fa[idx % NBUF][m], fb[idx % NBUF][n], acc[m][n]);
+        for (int m = 0; m < MT; ++m) {
+          if constexpr ((SSHIP_PP_ABL & 2) != 0) asm volatile("" :: "v"(fa[idx % NBUF][m]), "v"(fb[idx % NBUF][n]));
+          else acc[m][n] = mfma32(fa[idx % NBUF][m], fb[idx % NBUF][n], acc[m][n]);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
