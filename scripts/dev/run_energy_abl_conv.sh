@@ -6,7 +6,7 @@ O=gpurun_out/energy_abl_conv.txt
 run() { tag=$1; shift; bash scripts/dev/power_poll.sh $tag "$@" >> $O 2>&1; tail -1 /tmp/pp_$tag.log | sed "s/^/$tag /" >> $O; }
 for st in conv1ab conv2a; do
   run base_$st python scripts/dev/loop_kernel.py $st
-  for v in 3; do
+  for v in 1 2 3; do
     SUPERSLAM_HIP_LIBRARY=$(pwd)/superslam_amd/lib/variants/ppabl$v.so run abl${v}_$st python scripts/dev/loop_kernel.py $st
   done
 done
