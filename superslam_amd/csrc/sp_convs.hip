@@ -229,6 +229,9 @@ __global__ __launch_bounds__(512) void k_desc_head_gather(const _Float16* __rest
 // streams its 72 KiB of convDa fragments from L2 (packed exactly as the dense conv kernels read them, ct = 32).
 // ---------------------------------------------------------------------------------------------------
 constexpr int kDsPatchLd = 584;  // halfs per keypoint and 64-channel chunk: 9 taps x 64 + 8 (1168 B: conflict-free b128 reads)
+// NN = 32-keypoint N-tiles per workgroup: 2 for batches, 1 when that would leave most CUs without a workgroup (a stereo pair: 20 -> 40 workgroups,
+// half the MFMAs and half the patch gather per workgroup; the per-keypoint arithmetic is the same, so the two are bit-identical)
+template <int NN>
 __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __restrict__ a4b, int Hc, int Wc,
                                                           const int* __restrict__ cell_h, const int* __restrict__ cell_w,
                                                           const int* __restrict__ n_dev, int max_kp,
@@ -237,23 +240,24 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
                                                           _Float16* __restrict__ out, size_t out_img_stride) {
   extern __shared__ __attribute__((aligned(16))) char ds_smem[];
   _Float16* s_p = reinterpret_cast<_Float16*>(ds_smem);      // [64][kDsPatchLd] patch chunk
-  _Float16* s_x = s_p + 64 * kDsPatchLd;                      // [64][kDhLd] convDa output (convDb input)
-  float (*s_red)[64] = reinterpret_cast<float (*)[64]>(s_x + 64 * kDhLd);
+  constexpr int NK = 32 * NN;                                 // keypoints per workgroup
+  _Float16* s_x = s_p + NK * kDsPatchLd;                      // [NK][kDhLd] convDa output (convDb input)
+  float (*s_red)[64] = reinterpret_cast<float (*)[64]>(s_x + NK * kDhLd);
   int* s_cell = reinterpret_cast<int*>(s_red + 8);            // [64] (cell_h << 16 | cell_w), -1 = no keypoint
-  const int b = blockIdx.y, i0 = blockIdx.x * 64;
+  const int b = blockIdx.y, i0 = blockIdx.x * NK;
   const int n = min(max(n_dev[b], 0), max_kp);
   if (i0 >= n) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
-  if (tid < 64)
+  if (tid < NK)
     s_cell[tid] = i0 + tid < n ? (cell_h[(size_t)b * max_kp + i0 + tid] << 16) | cell_w[(size_t)b * max_kp + i0 + tid] : -1;
   const _Float16* img = a4b + (size_t)b * Hc * Wc * 128;
   // ---- convDa at the keypoints ----
-  f16x_t acc[2];  // start from the bias, as the dense ping-pong kernel does (conv_pp.hip: same fp32 summation order)
+  f16x_t acc[NN];  // start from the bias, as the dense ping-pong kernel does (conv_pp.hip: same fp32 summation order)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float4 bv = *reinterpret_cast<const float4*>(bda + wave * 32 + hh * 4 + g * 8);
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) { acc[nn][4 * g] = bv.x; acc[nn][4 * g + 1] = bv.y; acc[nn][4 * g + 2] = bv.z; acc[nn][4 * g + 3] = bv.w; }
+    for (int nn = 0; nn < NN; ++nn) { acc[nn][4 * g] = bv.x; acc[nn][4 * g + 1] = bv.y; acc[nn][4 * g + 2] = bv.z; acc[nn][4 * g + 3] = bv.w; }
   }
   const _Float16* wa = wda + (size_t)wave * (72 * 512) + lane * 8;  // [cb = wave][chunk][tap][kstep][lane][8]
   // k order inside a 64-channel chunk: the dense kernels' (conv_pp.hip CIN = 128 / conv_pp128.hip: 32-channel half, kx, k-step, ky)
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
 #pragma unroll
   for (int chunk = 0; chunk < 2; ++chunk) {  // unrolled: the fragment double buffer is indexed by the parity of g_lin
     if (chunk) __syncthreads();  // every wave is done reading the previous chunk's patches
-    for (int u = tid; u < 64 * 72; u += 512) {
+    for (int u = tid; u < NK * 72; u += 512) {
       const int kp = u / 72, rem = u - kp * 72, tap = rem >> 3, part = rem & 7;
       const int ky = tap / 3, kx = tap - ky * 3;
       const int c = s_cell[kp];
@@ -296,10 +300,11 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
       for (int i = 0; i < 12; ++i) {
         int tap, ks;
         frag_of(grp * 12 + i, tap, ks);
-        const h8_t b0 = *reinterpret_cast<const h8_t*>(s_p + j * kDsPatchLd + tap * 64 + ks * 16 + hh * 8);
-        const h8_t b1 = *reinterpret_cast<const h8_t*>(s_p + (32 + j) * kDsPatchLd + tap * 64 + ks * 16 + hh * 8);
-        acc[0] = mfma32(fa[g_lin & 1][i], b0, acc[0]);
-        acc[1] = mfma32(fa[g_lin & 1][i], b1, acc[1]);
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) {
+          const h8_t bf = *reinterpret_cast<const h8_t*>(s_p + (nn * 32 + j) * kDsPatchLd + tap * 64 + ks * 16 + hh * 8);
+          acc[nn] = mfma32(fa[g_lin & 1][i], bf, acc[nn]);
+        }
       }
     }
   }
@@ -313,36 +318,37 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+    for (int nn = 0; nn < NN; ++nn)
       *reinterpret_cast<h4_t*>(s_x + (nn * 32 + j) * kDhLd + wave * 32 + hh * 4 + g * 8) =
           to_h4(fmaxf(acc[nn][4 * g], 0.f), fmaxf(acc[nn][4 * g + 1], 0.f), fmaxf(acc[nn][4 * g + 2], 0.f), fmaxf(acc[nn][4 * g + 3], 0.f));
   }
   __syncthreads();
   // ---- convDb + F.normalize + gather renormalisation (as k_desc_head_gather) ----
 #pragma unroll
-  for (int nn = 0; nn < 2; ++nn)
+  for (int nn = 0; nn < NN; ++nn)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nn][r] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    const h8_t b0 = *reinterpret_cast<const h8_t*>(s_x + j * kDhLd + ks * 16 + hh * 8);
-    const h8_t b1 = *reinterpret_cast<const h8_t*>(s_x + (32 + j) * kDhLd + ks * 16 + hh * 8);
-    acc[0] = mfma32(a[ks], b0, acc[0]);
-    acc[1] = mfma32(a[ks], b1, acc[1]);
+#pragma unroll
+    for (int nn = 0; nn < NN; ++nn) {
+      const h8_t bf = *reinterpret_cast<const h8_t*>(s_x + (nn * 32 + j) * kDhLd + ks * 16 + hh * 8);
+      acc[nn] = mfma32(a[ks], bf, acc[nn]);
+    }
   }
-  float v[2][16];
+  float v[NN][16];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float4 bv = *reinterpret_cast<const float4*>(bdb + wave * 32 + hh * 4 + g * 8);
     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+    for (int nn = 0; nn < NN; ++nn)
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[nn][4 * g + e] = (float)(_Float16)(acc[nn][4 * g + e] + bb[e]);
   }
-  auto row_sum_sq = [&](float (&tot)[2]) {
+  auto row_sum_sq = [&](float (&tot)[NN]) {
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
+    for (int nn = 0; nn < NN; ++nn) {
       float ss = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ss += v[nn][r] * v[nn][r];
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
     }
     __syncthreads();
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
+    for (int nn = 0; nn < NN; ++nn) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += s_red[w][nn * 32 + j];
@@ -359,17 +365,17 @@ __global__ __launch_bounds__(512) void k_desc_head_sparse(const _Float16* __rest
     }
     __syncthreads();
   };
-  float tot[2];
+  float tot[NN];
   row_sum_sq(tot);
 #pragma unroll
-  for (int nn = 0; nn < 2; ++nn) {
+  for (int nn = 0; nn < NN; ++nn) {
     const float denom = fmaxf(sqrtf(tot[nn]), 1e-12f);  // F.normalize(p=2, dim=1, eps=1e-12)
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[nn][r] = (float)(_Float16)(v[nn][r] / denom);  // the fp16 dense descriptor
   }
   row_sum_sq(tot);
 #pragma unroll
-  for (int nn = 0; nn < 2; ++nn) {
+  for (int nn = 0; nn < NN; ++nn) {
     const int i = i0 + nn * 32 + j;
     if (i >= n) continue;
     const float inv = rsqrtf(tot[nn] + 1e-12f);  // DescriptorGather.cu:46
@@ -385,12 +391,21 @@ hipError_t launch_desc_head_sparse(const ConvW& da32, const ConvW& db32, const _
                                    const int* cell_w, const int* n_dev, int max_kp, int B, _Float16* out, size_t out_img_stride,
                                    hipStream_t s) {
   if (da32.cin != 128 || da32.cout != 256 || da32.ct != 32 || da32.ks != 3) return hipErrorInvalidValue;
-  constexpr size_t smem = (size_t)64 * kDsPatchLd * 2 + (size_t)64 * kDhLd * 2 + 8 * 64 * 4 + 64 * 4;
+  constexpr size_t smem = (size_t)64 * kDsPatchLd * 2 + (size_t)64 * kDhLd * 2 + 8 * 64 * 4 + 64 * 4;  // NN = 2 (NN = 1 uses half of the tile buffers)
   // thread-safe one-time opt-in to > 64 KiB of dynamic LDS (C++11 magic static; handles may be created on any thread)
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_desc_head_sparse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static const hipError_t attr_rc = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_desc_head_sparse<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_desc_head_sparse<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  }();
   if (attr_rc != hipSuccess) return attr_rc;
-  hipLaunchKernelGGL(k_desc_head_sparse, dim3((max_kp + 63) / 64, B), dim3(512), smem, s, a4b, Hc, Wc, cell_h, cell_w, n_dev,
-                     max_kp, da32.w, da32.bias, db32.w, db32.bias, out, out_img_stride);
+  // latency mode: 32-keypoint workgroups when the 64-keypoint grid would not give half of the CUs a workgroup
+  if (B * ((max_kp + 63) / 64) * 2 <= cu_count())
+    hipLaunchKernelGGL(k_desc_head_sparse<1>, dim3((max_kp + 31) / 32, B), dim3(512), smem, s, a4b, Hc, Wc, cell_h, cell_w, n_dev,
+                       max_kp, da32.w, da32.bias, db32.w, db32.bias, out, out_img_stride);
+  else
+    hipLaunchKernelGGL(k_desc_head_sparse<2>, dim3((max_kp + 63) / 64, B), dim3(512), smem, s, a4b, Hc, Wc, cell_h, cell_w, n_dev,
+                       max_kp, da32.w, da32.bias, db32.w, db32.bias, out, out_img_stride);
   return hipGetLastError();
 }
 
