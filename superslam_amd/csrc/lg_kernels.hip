@@ -175,6 +175,19 @@ __device__ __forceinline__ float max_xor32(float x) {
 //   3  = 2 with the QK^T MFMA chains of both query tiles issued first and interleaved (see `tile`).
 //      (another variant with the row sums on the matrix pipe as well - l += ones(32 x 16) P, two more MFMAs per key tile instead of
 //      eight v_dot2_f32_f16 - measured no faster than 2 and sat on the mscores0 bar: profiles/r03_a_attention_variants.txt; removed).
+// Energy ablations of the attention kernel (build.py --variant ... -DSSHIP_ATTN_ABL=n, scripts/dev/run_energy_abl_attn.sh): 1 no MFMAs (operands still
+// delivered), 2 P = the exponent's argument instead of exp2 of it (no v_exp_f32 in the key loop).  Results are wrong by design.
+#ifndef SSHIP_ATTN_ABL
+#define SSHIP_ATTN_ABL 0
+#endif
+__device__ __forceinline__ f16x_t mfma32_attn(h8_t a, h8_t b, f16x_t c) {
+  if constexpr ((SSHIP_ATTN_ABL & 1) != 0) {
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+  } else {
+    return mfma32(a, b, c);
+  }
+}
 template <int QT, int KS, int V>
 __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                          const _Float16* __restrict__ vt, const int* __restrict__ lens,
@@ -275,11 +288,11 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     f16x_t stq[QT];
     if constexpr (V == 3) {
 #pragma unroll
-      for (int t = 0; t < QT; ++t) stq[t] = mfma32(ones_k0, rf[t], zero16);
+      for (int t = 0; t < QT; ++t) stq[t] = mfma32_attn(ones_k0, rf[t], zero16);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int t = 0; t < QT; ++t) stq[t] = mfma32(kf[ks], qf[t][ks], stq[t]);
+        for (int t = 0; t < QT; ++t) stq[t] = mfma32_attn(kf[ks], qf[t][ks], stq[t]);
       __builtin_amdgcn_sched_barrier(0);  // the MFMAs above stay ahead of the first tile's softmax
     }
 #pragma unroll
@@ -287,9 +300,9 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
       f16x_t st;
       if constexpr (V == 3) st = stq[t];
       else {
-        st = V >= 2 ? mfma32(ones_k0, rf[t], zero16) : zero16;   // -r per query, or 0
+        st = V >= 2 ? mfma32_attn(ones_k0, rf[t], zero16) : zero16;   // -r per query, or 0
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[t][ks], st);
+        for (int ks = 0; ks < 4; ++ks) st = mfma32_attn(kf[ks], qf[t][ks], st);
       }
       if (k0 + 32 > nk) {  // only the last (ragged) key tile needs masking - wave-uniform branch
         int kb = k0 + 4 * hh;
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const float a0 = V == 1 ? st[8 * kk + e] - m[t] : st[8 * kk + e], a1 = V == 1 ? st[8 * kk + e + 1] - m[t] : st[8 * kk + e + 1];
-          const h2_t pp = {(_Float16)__builtin_amdgcn_exp2f(a0), (_Float16)__builtin_amdgcn_exp2f(a1)};
+          const h2_t pp = {(_Float16)((SSHIP_ATTN_ABL & 2) ? a0 : __builtin_amdgcn_exp2f(a0)), (_Float16)((SSHIP_ATTN_ABL & 2) ? a1 : __builtin_amdgcn_exp2f(a1))};
           pb[kk][e] = pp[0]; pb[kk][e + 1] = pp[1];
           if (kk == 0) ls0 = __builtin_amdgcn_fdot2(pp, ones2, ls0, false);
           else ls1 = __builtin_amdgcn_fdot2(pp, ones2, ls1, false);
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) o[t][mt] = mfma32(vf[kk][mt], pb[kk], o[t][mt]);
+        for (int mt = 0; mt < 2; ++mt) o[t][mt] = mfma32_attn(vf[kk][mt], pb[kk], o[t][mt]);
     }
   };
   fetch(kfA, vfA, ksp);
