@@ -50,6 +50,7 @@ struct Pp128Args {
   _Float16* out;
   int B, H, W, cout;
   unsigned long long* trace;  // [workgroup][group][6] clocks of half-steps 8..9: weight DMA issue, stage, prefetch, mfma, barrier waits
+  int pairs_on;               // conv3x3_pp128w: shared edge tiles allowed (launch_pp128w)
 };
 
 constexpr int Q_TH = 8, Q_TW = 32, Q_THH = 10, Q_TWH = 34;
@@ -424,6 +425,13 @@ constexpr unsigned R_OOB = 0x80000000u;            // beyond num_records, and no
 
 typedef int rsrc4_t __attribute__((ext_vector_type(4)));
 
+// shared edge tiles (see the kernel): no pooling (conv4a / 4b / Pa / Da), an even number of images, an edge strip of at most 15 pixels
+// behind at least one full tile column.  SUPERSLAM_HIP_CONV128_PAIRS=0 switches them off (A/B).
+__host__ __device__ inline bool pp128w_pairs_shape(bool pool, int B, int W) {
+  const int we = W - ((W + Q_TW - 1) / Q_TW - 1) * Q_TW;
+  return !pool && (B & 1) == 0 && W > Q_TW && we >= 1 && we <= 15;
+}
+#define pp128w_pairs(pool, B, W) (p.pairs_on && pp128w_pairs_shape(pool, B, W))
 template <bool POOL, int NCH>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
   constexpr int MT = 2, NT = 4;
@@ -438,7 +446,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
   float* s_bias = reinterpret_cast<float*>(s_w + 2 * Q_W_SLOT + 2 * R_IN_HALFS);  // [4 copies][64]
 
   const int tiles_x = (p.W + Q_TW - 1) / Q_TW, tiles_y = (p.H + R_TH - 1) / R_TH;
-  const int ntiles = p.B * tiles_x * tiles_y;
+  // Paired edge strips (pp128w_pairs): when the last tile column holds we = W - 32 (tiles_x - 1) <= 15 pixels, the strips of TWO images
+  // (each we + 2 halo columns wide) share one 34-column tile: LDS columns 0 .. we + 1 = image b, we + 2 .. 2 we + 3 = image b + 1.  An MFMA's
+  // N dimension is 32 pixels of one halo row whatever they are, so nothing changes between the DMA and the epilogue; conv4a / 4b / Pa at
+  // 47 x 172 cells run 33 tiles per image pair instead of 36.  The walk then runs over image PAIRS with a virtual tile row of
+  // 2 (tiles_x - 1) + 1 entries: [image 2 bp: columns 0 .. tiles_x - 2 | image 2 bp + 1: the same | the shared edge tile].
+  const bool pairs = pp128w_pairs(POOL, p.B, p.W);
+  const int txn = tiles_x - 1, we = p.W - txn * Q_TW;                 // full-width tile columns per image, width of the edge strip
+  const int tiles_xv = pairs ? 2 * txn + 1 : tiles_x, nb_walk = pairs ? p.B / 2 : p.B;
+  const int ntiles = nb_walk * tiles_xv * tiles_y;
   const int cb = blockIdx.y;
   const int t_begin = (int)((long long)blockIdx.x * ntiles / gridDim.x);
   const int t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
@@ -476,17 +492,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
 
   auto walk_init = [&](int t) __attribute__((always_inline)) {
     TileWalk w;
-    w.tx = t % tiles_x;
-    const int r = t / tiles_x;
+    w.tx = t % tiles_xv;
+    const int r = t / tiles_xv;
     w.ty = r % tiles_y; w.b = r / tiles_y;
     return w;
   };
   auto walk_next = [&](TileWalk& w) __attribute__((always_inline)) {
     w.tx += 2;
-    while (w.tx >= tiles_x) {
-      w.tx -= tiles_x;
+    while (w.tx >= tiles_xv) {
+      w.tx -= tiles_xv;
       if (++w.ty == tiles_y) { w.ty = 0; ++w.b; }
     }
+  };
+  // virtual (tx, b) of the walk -> image, tile column, and whether this is a shared edge tile
+  auto decode = [&](const TileWalk& w, int& img, int& tx, bool& shared) __attribute__((always_inline)) {
+    if (!pairs) { img = w.b; tx = w.tx; shared = false; return; }
+    shared = w.tx == 2 * txn;
+    const int second = !shared && w.tx >= txn;
+    img = 2 * w.b + second;
+    tx = shared ? txn : w.tx - second * txn;
   };
   TileWalk pw = walk_init(t_begin + grp), ew = pw;  // tile of the next input DMA / of the next epilogue
 
@@ -502,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
   // other group's MFMA stream: 2.2-2.8 k clocks of "DMA issue" per half-step, profiles/r03_n_pp128w_role_trace.txt).
   unsigned voff[R_DMA_PER_WAVE];
   unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0;  // bit i: row >= 1 | row <= H - y0(last) | column >= 1 | column <= W - x0(last)
+  unsigned m_second = 0, m_dead = 0;  // shared edge tile: bit i = the unit belongs to image b + 1's strip | to no strip (right halo of either, spare columns)
   {
     const int px = (gw * R_DMA_PER_WAVE) * 16 + (lane >> 2);
     int r = (px * 241) >> 13;  // px / 34 for px < 640
@@ -515,6 +540,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
       m_bot |= (r <= rhi_last ? 1u : 0u) << i;
       m_left |= (c >= 1 ? 1u : 0u) << i;
       m_right |= (c <= chi_last ? 1u : 0u) << i;
+      m_second |= (c >= we + 2 && c < 2 * we + 3 ? 1u : 0u) << i;       // columns we + 2 .. 2 we + 2: left halo + the we pixels of image b + 1
+      m_dead |= (c == we + 1 || c >= 2 * we + 3 ? 1u : 0u) << i;        // column W of either image (zero padding) and the unused columns
       c += 16;
       if (c >= Q_TWH) { c -= Q_TWH; ++r; }
     }
@@ -530,19 +557,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
   const unsigned lds_in0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(my_in + (gw_u * R_DMA_PER_WAVE) * 512));
   // one tile chunk -> LDS at m0a / m0b / m0c (the three instruction groups of a wave)
   auto dma_tile = [&](const TileWalk& w, int chunk, unsigned m0a, unsigned m0b, unsigned m0c) __attribute__((always_inline)) {
-    const int y0 = w.ty * R_TH, x0 = w.tx * Q_TW;
-    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((w.b * p.H + y0) * p.W + x0) * (unsigned)PB + (unsigned)chunk * 64u);
-    const bool interior = y0 >= 1 && y0 + R_TH + 1 <= p.H && x0 >= 1 && x0 + Q_TW + 1 <= p.W;
+    int img, txr;
+    bool shared;
+    decode(w, img, txr, shared);
+    const int y0 = w.ty * R_TH, x0 = txr * Q_TW;
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((img * p.H + y0) * p.W + x0) * (unsigned)PB + (unsigned)chunk * 64u);
+    const bool interior = !shared && y0 >= 1 && y0 + R_TH + 1 <= p.H && x0 >= 1 && x0 + Q_TW + 1 <= p.W;
     unsigned v[R_DMA_PER_WAVE];
     if (interior) {
 #pragma unroll
       for (int i = 0; i < R_DMA_PER_WAVE; ++i) v[i] = voff[i];
+    } else if (shared) {
+      // strip of image b: the ordinary addressing (LDS column c = image column x0 - 1 + c); strip of image b + 1: the same unit we + 2
+      // columns further left, one image further on; everything else reads zeros
+      unsigned ok = 0x3ffu & ~m_dead;
+      if (w.ty == 0) ok &= m_top;
+      if (w.ty == tiles_y - 1) ok &= m_bot;
+      const unsigned delta = (unsigned)(p.H * p.W - (we + 2)) * (unsigned)PB;
+#pragma unroll
+      for (int i = 0; i < R_DMA_PER_WAVE; ++i) v[i] = (ok >> i) & 1u ? voff[i] + ((m_second >> i) & 1u ? delta : 0u) : R_OOB;
     } else {
       unsigned ok = 0x3ffu;
       if (w.ty == 0) ok &= m_top;
       if (w.ty == tiles_y - 1) ok &= m_bot;
-      if (w.tx == 0) ok &= m_left;
-      if (w.tx == tiles_x - 1) ok &= m_right;
+      if (txr == 0) ok &= m_left;
+      if (txr == tiles_x - 1) ok &= m_right;
 #pragma unroll
       for (int i = 0; i < R_DMA_PER_WAVE; ++i) v[i] = (ok >> i) & 1u ? voff[i] : R_OOB;
     }
@@ -635,9 +674,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
   };
   // ---------------- epilogue: ReLU (+ 2x2 max-pool) -> fp16 channels-last, 16-byte stores; the bias is already in ----------------
   auto epilogue = [&]() __attribute__((always_inline)) {
-    const int y0 = ew.ty * R_TH, x0 = ew.tx * Q_TW, b = ew.b;
+    int b, txr;
+    bool shared;
+    decode(ew, b, txr, shared);
+    const int y0 = ew.ty * R_TH, x0 = txr * Q_TW;
     walk_next(ew);
-    const int yb = y0 + gw * 4, x = x0 + j;
+    const int yb = y0 + gw * 4;
+    int x = x0 + j;
+    if (shared) {  // output column j < we: image b; we + 2 <= j < 2 we + 2: image b + 1 (its column j - (we + 2)); the rest is nobody's
+      const bool second = j >= we + 2;
+      b += second;
+      x = second ? x0 + j - (we + 2) : (j < we ? x : p.W);
+    }
     const h2_t z2 = {(_Float16)0.f, (_Float16)0.f};
     auto relu2 = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
       h2_t v = {(_Float16)lo, (_Float16)hi};
@@ -797,7 +845,10 @@ static hipError_t launch_pp128w(const Pp128Args& a, hipStream_t s) {
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr_rc != hipSuccess) return attr_rc;
   const int ncb = a.cout / 64;
-  const int ntiles = a.B * ((a.W + Q_TW - 1) / Q_TW) * ((a.H + R_TH - 1) / R_TH);
+  static const bool pairs_env = !(getenv("SUPERSLAM_HIP_CONV128_PAIRS") && atoi(getenv("SUPERSLAM_HIP_CONV128_PAIRS")) == 0);
+  const bool pairs = pairs_env && pp128w_pairs_shape(POOL, a.B, a.W);
+  const int tiles_x = (a.W + Q_TW - 1) / Q_TW;
+  const int ntiles = (pairs ? a.B / 2 * (2 * (tiles_x - 1) + 1) : a.B * tiles_x) * ((a.H + R_TH - 1) / R_TH);  // as the kernel counts them
   int gx = cu_count() / ncb;  // one persistent workgroup per CU
   if (gx < 1) gx = 1;
   if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;
@@ -805,6 +856,7 @@ static hipError_t launch_pp128w(const Pp128Args& a, hipStream_t s) {
   static const bool trace_on = SSHIP_PP_TRACE_BUILD && getenv("SSHIP_PP_TRACE") != nullptr;
   static unsigned long long* tbuf = nullptr;
   Pp128Args b = a;
+  b.pairs_on = pairs_env ? 1 : 0;
   if (trace_on) {
     if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 2 * 6 * 8);
     (void)hipMemsetAsync(tbuf, 0, 4096 * 2 * 6 * 8, s);

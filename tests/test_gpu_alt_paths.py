@@ -89,12 +89,16 @@ def test_ct32_conv_kernel_is_bit_identical_to_the_16_row_tile_kernel(weights_dir
     would leave most CUs without a workgroup on the big tiles; sp_conv3x3_pp picks by tile count).  Both feed the same fp16 operands
     into an fp32 accumulator that starts at the bias IN THE SAME ORDER (32-channel half, kx, k-step, ky), so they are bit-identical:
     a frame extracted alone equals the same frame inside a batch.  SUPERSLAM_HIP_CONV128=th16 / ct32 force one or the other.
+    The 16-row kernel packs the narrow right-edge strips of two images into one tile where the shapes allow (SUPERSLAM_HIP_CONV128_PAIRS=0: off):
+    the worker's stereo pair has such strips, and the result must not depend on the packing either.
     The worker's 200 x 328 image gives those layers odd tile counts, partial edge tiles and a one-tile-per-group tail."""
     base = _run({"SUPERSLAM_HIP_CONV128": "th16"}, weights_dir, tmp_path, "th16")
     alt = _run({"SUPERSLAM_HIP_CONV128": "ct32"}, weights_dir, tmp_path, "ct32")
     auto = _run({}, weights_dir, tmp_path, "auto")
+    # the 16-row kernel's shared edge tiles (the 9-column strips of the pair's two 25 x 41-cell maps in ONE tile; conv4a / 4b / Pa) on and off
+    nopairs = _run({"SUPERSLAM_HIP_CONV128": "th16", "SUPERSLAM_HIP_CONV128_PAIRS": "0"}, weights_dir, tmp_path, "th16_nopairs")
     for tag in ("l", "r"):
-        for other in (alt, auto):
+        for other in (alt, auto, nopairs):
             np.testing.assert_array_equal(base["kp_" + tag], other["kp_" + tag])
             np.testing.assert_array_equal(base["d_" + tag].view(np.uint16), other["d_" + tag].view(np.uint16))
 
