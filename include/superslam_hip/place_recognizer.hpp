@@ -1,9 +1,11 @@
-// Host layer of the place recogniser, OpenCV-free mirrors of the reference's classes:
-//   superslam_hip::LoopCandidate, IPlaceRecognizer, CosineDescriptorIndex, TemporalConsistencyVoter  (include/PlaceRecognizer.h,
-//   src/PlaceRecognizer.cc) and EigenPlaces (include/EigenPlaces.h:19-40, src/EigenPlaces.cc) over the C ABI (sship_ep_*).
-// Same method names, argument meaning and error behaviour (initialize() returns bool, compute_global_descriptor returns an
-// empty vector when the recogniser is not initialised); a descriptor is a std::vector<float> where the reference has a
-// 1 x D CV_32F cv::Mat.  The pure host parts (resize / preprocess / index / voter) need no GPU.
+// Host layer of the place recogniser's DESCRIPTOR SOURCE: the OpenCV-free half of the reference's EigenPlaces
+// (include/EigenPlaces.h:19-30, src/EigenPlaces.cc:123-174) over the C ABI (sship_ep_*): initialize() returns bool,
+// compute_global_descriptor returns an empty vector when the recogniser is not initialised; a descriptor is a std::vector<float> where
+// the reference has a 1 x D CV_32F cv::Mat.
+// The retrieval side - superslam::CosineDescriptorIndex, TemporalConsistencyVoter, IPlaceRecognizer::add / query (include/PlaceRecognizer.h,
+// src/PlaceRecognizer.cc) - is GPU-free control plane that stays the reference's own code in libsuperslam_core: the reference-side
+// adapter (integration/reference_side/EigenPlaces.h) holds a superslam::CosineDescriptorIndex exactly as include/EigenPlaces.h:30-36,62 does.
+// Nothing of it is restated in this product (a restatement for the tests lives in oracle/eigenplaces_ref.py).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -72,93 +74,22 @@ inline void eigenplaces_preprocess(const Image& image, int input_w, int input_h,
     }
 }
 
-// ---- include/PlaceRecognizer.h ----
-struct LoopCandidate {
-  size_t keyframe_id = 0;
-  float score = 0.0f;  // cosine similarity in [-1, 1]
-};
 typedef std::vector<float> GlobalDescriptor;
 
-class IPlaceRecognizer {
-public:
-  virtual ~IPlaceRecognizer() = default;
-  virtual GlobalDescriptor compute_global_descriptor(const Image& image) = 0;
-  virtual void add(size_t keyframe_id, const GlobalDescriptor& global_descriptor) = 0;
-  virtual std::vector<LoopCandidate> query(const GlobalDescriptor& global_descriptor, size_t excludeRecent, int topK) = 0;
-};
-
-class CosineDescriptorIndex {  // src/PlaceRecognizer.cc:22-56
-public:
-  void add(size_t keyframe_id, const GlobalDescriptor& d) { ids_.push_back(keyframe_id); db_.push_back(normalized(d)); }
-  std::vector<LoopCandidate> query(const GlobalDescriptor& d, size_t excludeRecent, int topK, float minScore) const {
-    std::vector<LoopCandidate> out;
-    const size_t M = ids_.size();
-    if (M == 0 || M <= excludeRecent) return out;  // nothing old enough to be a loop
-    const GlobalDescriptor q = normalized(d);
-    const size_t limit = M - excludeRecent;
-    out.reserve(limit);
-    for (size_t i = 0; i < limit; ++i) {
-      float s = 0.f;
-      const size_t n = std::min(q.size(), db_[i].size());
-      for (size_t k = 0; k < n; ++k) s += db_[i][k] * q[k];
-      if (s >= minScore) out.push_back({ids_[i], s});
-    }
-    std::sort(out.begin(), out.end(), [](const LoopCandidate& a, const LoopCandidate& b) { return a.score > b.score; });
-    if (topK > 0 && out.size() > static_cast<size_t>(topK)) out.resize(topK);
-    return out;
-  }
-  size_t size() const { return ids_.size(); }
-
-private:
-  static GlobalDescriptor normalized(const GlobalDescriptor& d) {
-    double n = 0.0;
-    for (float v : d) n += static_cast<double>(v) * v;
-    n = std::sqrt(n);
-    GlobalDescriptor r = d;
-    if (n > 1e-12) for (float& v : r) v = static_cast<float>(v / n);
-    return r;
-  }
-  std::vector<size_t> ids_;
-  std::vector<GlobalDescriptor> db_;
-};
-
-class TemporalConsistencyVoter {  // src/PlaceRecognizer.cc:58-71
-public:
-  TemporalConsistencyVoter(int requiredVotes, size_t idTolerance) : required_(requiredVotes), tol_(idTolerance) {}
-  bool vote(const LoopCandidate* best) {
-    if (!best) { streak_ = 0; have_last_ = false; return false; }
-    const size_t id = best->keyframe_id;
-    const bool consistent = have_last_ && (id >= last_id_ ? id - last_id_ : last_id_ - id) <= tol_;
-    streak_ = consistent ? streak_ + 1 : 1;
-    last_id_ = id;
-    have_last_ = true;
-    return streak_ >= required_;
-  }
-
-private:
-  int required_;
-  size_t tol_;
-  int streak_ = 0;
-  size_t last_id_ = 0;
-  bool have_last_ = false;
-};
-
 // ---- include/EigenPlaces.h ----
-class EigenPlaces : public IPlaceRecognizer {
+class EigenPlaces {
 public:
   // `engine_file` names the safetensors weight file (utils/convert_eigenplaces_to_onnx.py:99 writes it next to the ONNX)
   EigenPlaces(const std::string& engine_file, int input_width, int input_height)
-      : engine_file_(engine_file), input_width_(input_width), input_height_(input_height) {
-    if (const char* s = std::getenv("SUPERSLAM_LOOP_MIN_SCORE")) min_score_ = static_cast<float>(std::atof(s));  // src/EigenPlaces.cc:33-34
-  }
-  ~EigenPlaces() override { if (ep_) sship_ep_destroy(ep_); }
+      : engine_file_(engine_file), input_width_(input_width), input_height_(input_height) {}
+  ~EigenPlaces() { if (ep_) sship_ep_destroy(ep_); }
   EigenPlaces(const EigenPlaces&) = delete;
   EigenPlaces& operator=(const EigenPlaces&) = delete;
   bool initialize() {
     if (sship_ep_create(engine_file_.c_str(), input_width_, input_height_, &ep_) != SSHIP_OK) { last_error_ = sship_last_error(); ep_ = nullptr; return false; }
     return true;
   }
-  GlobalDescriptor compute_global_descriptor(const Image& image) override {
+  GlobalDescriptor compute_global_descriptor(const Image& image) {
     if (!ep_) return GlobalDescriptor();  // `if (!context_) return cv::Mat();`
     std::vector<float> chw(static_cast<size_t>(3) * input_height_ * input_width_);
     eigenplaces_preprocess(image, input_width_, input_height_, chw.data());
@@ -170,18 +101,12 @@ public:
     if (n > 0) for (float& v : d) v = static_cast<float>(v / n);
     return d;
   }
-  void add(size_t keyframe_id, const GlobalDescriptor& d) override { index_.add(keyframe_id, d); }
-  std::vector<LoopCandidate> query(const GlobalDescriptor& d, size_t excludeRecent, int topK) override {
-    return index_.query(d, excludeRecent, topK, min_score_);
-  }
   const std::string& last_error() const { return last_error_; }
 
 private:
   std::string engine_file_;
   int input_width_, input_height_;
-  float min_score_ = 0.75f;  // include/EigenPlaces.h:61
   sship_ep* ep_ = nullptr;
-  CosineDescriptorIndex index_;
   std::string last_error_;
 };
 

@@ -1,10 +1,12 @@
 // Reference-side binding (goes into the SuperSLAM tree as include/EigenPlaces.h; replaces the TensorRT runner).
 // Same class name, constructor and methods as the reference's header (include/EigenPlaces.h:19-40): SuperSLAM.cc:116-133 and
-// LoopCloser compile and run unchanged against superslam::IPlaceRecognizer.  All work is forwarded to libsuperslam_hip.so
-// through include/superslam_hip/place_recognizer.hpp -> include/sship.h (sship_ep_*).
+// LoopCloser compile and run unchanged against superslam::IPlaceRecognizer.  The descriptor is computed by libsuperslam_hip.so
+// (include/superslam_hip/place_recognizer.hpp -> include/sship.h, sship_ep_*); retrieval stays the reference's own
+// superslam::CosineDescriptorIndex (src/PlaceRecognizer.cc in libsuperslam_core), held and used exactly as include/EigenPlaces.h:30-36,53,62.
 #ifndef EIGENPLACES_HIP_ADAPTER_H_
 #define EIGENPLACES_HIP_ADAPTER_H_
 
+#include <cstdlib>
 #include <memory>
 #include <opencv4/opencv2/core.hpp>
 #include <string>
@@ -16,7 +18,9 @@
 
 class EigenPlaces : public superslam::IPlaceRecognizer {
 public:
-  EigenPlaces(const std::string& engine_file, int input_width, int input_height) : impl_(engine_file, input_width, input_height) {}
+  EigenPlaces(const std::string& engine_file, int input_width, int input_height) : impl_(engine_file, input_width, input_height) {
+    if (const char* s = std::getenv("SUPERSLAM_LOOP_MIN_SCORE")) min_score_ = static_cast<float>(std::atof(s));  // src/EigenPlaces.cc:33-34
+  }
   bool initialize() {
     const bool ok = impl_.initialize();
     if (!ok) SLOG_ERROR("EigenPlaces(HIP): {}", impl_.last_error());
@@ -32,26 +36,14 @@ public:
     for (size_t i = 0; i < d.size(); ++i) out.ptr<float>(0)[i] = d[i];
     return out;
   }
-  void add(size_t keyframe_id, const cv::Mat& global_descriptor) override { impl_.add(keyframe_id, to_vec(global_descriptor)); }
+  void add(size_t keyframe_id, const cv::Mat& global_descriptor) override { index_.add(keyframe_id, global_descriptor); }
   std::vector<superslam::LoopCandidate> query(const cv::Mat& global_descriptor, size_t excludeRecent, int topK) override {
-    std::vector<superslam::LoopCandidate> out;
-    for (const auto& c : impl_.query(to_vec(global_descriptor), excludeRecent, topK)) {
-      superslam::LoopCandidate lc;
-      lc.keyframe_id = c.keyframe_id; lc.score = c.score;
-      out.push_back(lc);
-    }
-    return out;
+    return index_.query(global_descriptor, excludeRecent, topK, min_score_);
   }
 
 private:
-  static superslam_hip::GlobalDescriptor to_vec(const cv::Mat& m) {
-    cv::Mat f;
-    if (m.type() == CV_32F) f = m; else m.convertTo(f, CV_32F);
-    superslam_hip::GlobalDescriptor v(f.total());
-    for (int r = 0, k = 0; r < f.rows; ++r)
-      for (int c = 0; c < f.cols; ++c) v[k++] = f.ptr<float>(r)[c];
-    return v;
-  }
   superslam_hip::EigenPlaces impl_;
+  float min_score_ = 0.75f;                  // include/EigenPlaces.h:53
+  superslam::CosineDescriptorIndex index_;   // include/EigenPlaces.h:62
 };
 #endif

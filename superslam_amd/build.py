@@ -10,21 +10,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsuperslam_hip.so")
-SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "conv_pp128.hip", "conv_wino.hip", "lg_kernels.hip", "lg_ffn16.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
+SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "conv_pp128.hip", "conv_wino.hip", "lg_kernels.hip", "lg_attn_res.hip", "lg_ffn16.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 # per-file flags.  -fno-honor-nans: under IEEE NaN semantics every fmaxf() operand that comes out of an MFMA is
 # canonicalised first (a second v_max_f32 per value) - the attention softmax's running max and every ReLU / max-pool
 # of the conv epilogues paid for that.  None of these kernels produces or tests for a NaN (masked scores are -inf,
 # never inf - inf); infinities keep their meaning.
-FILE_FLAGS = {f: ["-fno-honor-nans"] for f in ("lg_kernels.hip", "lg_ffn16.hip", "conv_wino.hip", "conv_pp.hip", "conv_pp128.hip", "conv_strip.hip", "sp_convs.hip")}
+FILE_FLAGS = {f: ["-fno-honor-nans"] for f in ("lg_kernels.hip", "lg_attn_res.hip", "lg_ffn16.hip", "conv_wino.hip", "conv_pp.hip", "conv_pp128.hip", "conv_strip.hip", "sp_convs.hip")}
 # LightGlue kernels: no packed-fp32 VALU (v_pk_mul_f32, v_pk_fma_f32, ...).  Two workgroups share a CU there so that one's
 # GELU / LayerNorm / softmax VALU rides next to the other's MFMA stream, and next to an MFMA stream a packed-fp32
 # instruction costs 17 clocks per wave-instruction against 6.4 for a plain one (profiles/r02_valu_rates_next_to_mfma.txt):
 # two scalar instructions beat one packed one.  -1 % on a 64-pair LightGlue call.
 # (lg_ffn16.hip: its 16 waves move through the phases together, nothing issues MFMAs next to its GELU phase - packed fp32 was tried there
 # (GELU 9.5 k -> 7.9 k clocks per chunk) but the register pairs it needs pushed the rotary epilogue into scratch: profiles/r04_c_*)
-for _f in ("lg_kernels.hip", "lg_ffn16.hip", "conv_wino.hip"):
+for _f in ("lg_kernels.hip", "lg_attn_res.hip", "lg_ffn16.hip", "conv_wino.hip"):
     FILE_FLAGS[_f] = FILE_FLAGS[_f] + ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 

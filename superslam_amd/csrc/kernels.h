@@ -108,6 +108,10 @@ hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope
                            const float* rope, _Float16* q, _Float16* k, _Float16* vt, hipStream_t s);
 void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d,
                          bool cross, _Float16* ctx, hipStream_t s, bool shared_gpu = false);
+// lg_attn_res.hip: throughput batches, the keys of a (sequence, head) resident in LDS
+bool lg_attention_res_fits(LgDims d);
+void launch_lg_attention_res(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
+                             _Float16* ctx, hipStream_t s);
 // prefetch (both launches below): up to three packed layers the NEXT FFN launch streams; latency mode pulls them into L2 with surplus workgroups
 hipError_t launch_lg_proj_heads(const ConvW& next, _Float16* x, LgDims d, int rope_segs, int t_seg, const float* rope, _Float16* q,
                                 _Float16* k, _Float16* vt, hipStream_t s, const ConvW* const* prefetch = nullptr);

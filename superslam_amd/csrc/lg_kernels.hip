@@ -507,7 +507,10 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
   // instead of two (a wave issues one VALU instruction per ~5 clocks, the SIMD retires one per 2: more waves = more VALU issue),
   // at twice the K / V^T fragment traffic per query
   static const int qt_env = getenv("SUPERSLAM_HIP_ATTN_QT") ? atoi(getenv("SUPERSLAM_HIP_ATTN_QT")) : 0;
-  if (d.S * (d.NP / 64) * 4 >= 2 * cu_count()) {
+  static const bool stream_env = getenv("SUPERSLAM_HIP_ATTN") && std::string(getenv("SUPERSLAM_HIP_ATTN")) == "stream";  // A/B: the streaming kernel
+  if (!stream_env && d.S * (d.NP / 64) * 4 >= 2 * cu_count() && lg_attention_res_fits(d)) {
+    launch_lg_attention_res(q, k, vt, lens, d, cross, ctx, s);
+  } else if (d.S * (d.NP / 64) * 4 >= 2 * cu_count()) {
     // shared_gpu: another stream runs the other half-batch's kernels next to this launch (lg_forward), so the partly filled last
     // round of a 256-query workgroup (no key split: no LDS merge, the prologue paid once per 19 key tiles) costs nothing:
     // 92 -> 101 us for a launch on its own, but -1.2 % on the two-stream LightGlue call

@@ -1,5 +1,6 @@
-// Minimal stand-in for <opencv2/core.hpp> (tests/cpp/shim/README.md): only what the binding and StereoFrontEnd touch.
+// Minimal stand-in for <opencv2/core.hpp> (tests/cpp/shim/README.md): only what the binding, StereoFrontEnd.cc and PlaceRecognizer.cc touch.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -78,9 +79,50 @@ public:
       }
     dst = out;
   }
+  // ---- the CV_32F row-matrix operations src/PlaceRecognizer.cc uses (reshape / push_back / rowRange / t / at; norm, /, * below) ----
+  Mat reshape(int /*cn*/, int new_rows) const {  // single channel, continuous data only
+    Mat m = *this;
+    m.rows = new_rows; m.cols = new_rows ? static_cast<int>(total() * channels() / new_rows) : 0;
+    m.type_ = CV_MAKETYPE(depth(), 1); m.step = static_cast<size_t>(m.cols) * m.elemSize();
+    return m;
+  }
+  void push_back(const Mat& row) {  // append the rows of `row` (same type and width)
+    Mat m(rows + row.rows, row.cols, row.type());
+    for (int r = 0; r < rows; ++r) std::memcpy(m.data + m.step * r, data + step * r, m.step);
+    for (int r = 0; r < row.rows; ++r) std::memcpy(m.data + m.step * (rows + r), row.data + row.step * r, m.step);
+    *this = m;
+  }
+  Mat rowRange(int a, int b) const { Mat m = *this; m.rows = b - a; m.data = data + step * a; return m; }  // shares the buffer
+  Mat t() const {
+    Mat m(cols, rows, type_);
+    for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) m.ptr<float>(c)[r] = ptr<float>(r)[c];
+    return m;
+  }
+  template <class T> T& at(int r, int c) { return ptr<T>(r)[c]; }
+  template <class T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
 
 private:
   int type_ = 0;
   std::shared_ptr<unsigned char> own_;  // shared like cv::Mat's refcounted buffer
 };
+inline double norm(const Mat& m) {  // NORM_L2 over a CV_32F matrix
+  double n = 0.0;
+  for (int r = 0; r < m.rows; ++r) for (int c = 0; c < m.cols; ++c) n += static_cast<double>(m.ptr<float>(r)[c]) * m.ptr<float>(r)[c];
+  return std::sqrt(n);
+}
+inline Mat operator/(const Mat& m, double d) {
+  Mat o(m.rows, m.cols, m.type());
+  for (int r = 0; r < m.rows; ++r) for (int c = 0; c < m.cols; ++c) o.ptr<float>(r)[c] = static_cast<float>(m.ptr<float>(r)[c] / d);
+  return o;
+}
+inline Mat operator*(const Mat& a, const Mat& b) {  // CV_32F GEMM
+  Mat o(a.rows, b.cols, CV_32F);
+  for (int r = 0; r < a.rows; ++r)
+    for (int c = 0; c < b.cols; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < a.cols; ++k) acc += static_cast<double>(a.ptr<float>(r)[k]) * b.ptr<float>(k)[c];
+      o.ptr<float>(r)[c] = static_cast<float>(acc);
+    }
+  return o;
+}
 }  // namespace cv

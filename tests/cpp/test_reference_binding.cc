@@ -118,6 +118,26 @@ static void cpu_checks() {
   CHECK(!ep.initialize());
   CHECK(ep.compute_global_descriptor(cv::Mat::zeros(64, 64, CV_8U)).empty());      // `if (!context_) return cv::Mat();`
   CHECK(ep.query(cv::Mat::zeros(1, 512, CV_32F), 0, 5).empty());
+  // add / query of the adapter run the reference's OWN retrieval code (src/PlaceRecognizer.cc, compiled from /root/reference into this
+  // binary): the index cases of the reference's tests/test_place_recognizer.cc:22-80 through the IPlaceRecognizer interface
+  auto desc = [](int dim, int seed, float jitter) { cv::Mat d = cv::Mat::zeros(1, dim, CV_32F); d.at<float>(0, seed % dim) = 1.0f; d.at<float>(0, (seed + 1) % dim) = 0.5f + jitter; return d; };
+  {
+    setenv("SUPERSLAM_LOOP_MIN_SCORE", "0.0", 1);   // src/EigenPlaces.cc:33-34: the gate is read at construction
+    EigenPlaces idx("/nonexistent/eigenplaces.safetensors", 512, 512);
+    IPlaceRecognizer& r = idx;
+    r.add(0, desc(16, 3, 0.f)); r.add(1, desc(16, 9, 0.f));
+    std::vector<LoopCandidate> res = r.query(desc(16, 3, 0.01f), 0, 5);
+    CHECK(!res.empty() && res.front().keyframe_id == 0u && res.front().score > 0.95f);
+    if (res.size() > 1) CHECK(res[1].score < res.front().score);
+    for (int i = 2; i < 6; ++i) r.add(i, desc(16, i + 20, 0.f));
+    for (const auto& c : r.query(desc(16, 25, 0.f), 2, 5)) CHECK(c.keyframe_id < 4u);   // excludeRecent skips the last two insertions
+    CHECK(r.query(desc(16, 3, 0.f), 0, 2).size() <= 2u);                                 // topK
+    CHECK(r.query(desc(16, 3, 0.f), 6, 5).empty());                                      // everything excluded
+    unsetenv("SUPERSLAM_LOOP_MIN_SCORE");
+    EigenPlaces gated("/nonexistent/eigenplaces.safetensors", 512, 512);                 // default gate 0.75 (include/EigenPlaces.h:53)
+    gated.add(0, desc(16, 3, 0.f)); gated.add(1, desc(16, 9, 0.f));
+    for (const auto& c : gated.query(desc(16, 3, 0.f), 0, 5)) CHECK(c.score >= 0.75f && c.keyframe_id == 0u);
+  }
 }
 
 static void gpu_checks(const char* spw, const char* lgw) {

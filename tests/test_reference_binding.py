@@ -14,7 +14,8 @@ BIN = os.path.join(ROOT, "superslam_amd", "lib", "test_reference_binding")
 
 def build(force=False):
     libdir = os.path.join(ROOT, "superslam_amd", "lib")
-    srcs = [os.path.join(ROOT, "tests", "cpp", "test_reference_binding.cc"), os.path.join(REF, "src", "StereoFrontEnd.cc")]
+    srcs = [os.path.join(ROOT, "tests", "cpp", "test_reference_binding.cc"), os.path.join(REF, "src", "StereoFrontEnd.cc"),
+            os.path.join(REF, "src", "PlaceRecognizer.cc")]   # the adapter holds the reference's own CosineDescriptorIndex
     deps = srcs + [os.path.join(ROOT, "integration", "reference_side", f) for f in ("SuperPoint.h", "LightGlue.h", "EigenPlaces.h")] + \
         [os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp"), os.path.join(ROOT, "tests", "cpp", "shim", "opencv4", "opencv2", "core.hpp")]
     if force or not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
