@@ -24,6 +24,17 @@
  *     matches0 i32, mscores0 f32.  Internal accumulation is f32.
  *   - handles are single-threaded; sship_lg_weights is immutable and shareable across handles/threads
  *     (the LightGlueEngine / shared_engine() analogue, include/LightGlue.h:28-31,44).
+ *
+ * Environment
+ *   The library reads exactly two environment variables, each once per process:
+ *     SUPERSLAM_HIP_DEVICE=<n>   device ordinal sship_init(-1) / the first call of a thread binds (default 0; the multi-process
+ *                                scripts set it from LOCAL_RANK);
+ *     SSHIP_RCCL_LIBRARY=<path>  the RCCL library sship_comm_* binds at run time instead of the process's own / librccl.so.1.
+ *   Nothing else: there is ONE kernel per layer and no run-time kernel selection, so a stray variable cannot move a SuperSLAM
+ *   process onto a slower or looser path.  Profiling is an API (sship_set_profiling), not a variable.  The A/B switches of the
+ *   development history (SUPERSLAM_HIP_CONV*, _ATTN*, _FFN*, _LG_*, SSHIP_*_TRACE) and the kernels they select exist only in the
+ *   developer build superslam_amd/lib/variants/dev.so (`python -m superslam_amd.build --dev`, -DSSHIP_DEV_SWITCHES=1), which the
+ *   A/B tests and scripts load explicitly.
  */
 #ifndef SSHIP_H_
 #define SSHIP_H_

@@ -17,5 +17,5 @@ DB=$(ls /tmp/prof_ks/*results.db 2>/dev/null | head -1)
 cd $R
 timeout 400 scripts/pmc_traffic.sh $P $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1; cp gpurun_out/pmc_conv1ab.json $O/ 2>/dev/null
 timeout 400 scripts/pmc_sq.sh $P gpurun_out/$TAG/pmc_sq_raw.txt; python scripts/pmc_sq_table.py $O/pmc_sq_raw.txt > $O/pmc_sq_P$P.txt; rm -f $O/pmc_sq_raw.txt
-SSHIP_FFN_TRACE=1 timeout 120 python bench.py --headline-only --steps 1 --warmup 1 --chunks 1 --pairs $P 2>&1 | grep -E "ffn4? trace" | sed -n "19,22p" > $O/ffn_phase_trace.txt
+SUPERSLAM_HIP_LIBRARY=$R/superslam_amd/lib/variants/dev.so SSHIP_FFN_TRACE=1 timeout 120 python bench.py --headline-only --steps 1 --warmup 1 --chunks 1 --pairs $P 2>&1 | grep -E "ffn4? trace" | sed -n "19,22p" > $O/ffn_phase_trace.txt
 ls -la $O

@@ -10,7 +10,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsuperslam_hip.so")
-SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_strip.hip", "conv_pp.hip", "conv_pp128.hip", "conv_wino.hip", "lg_kernels.hip", "lg_attn_res.hip", "lg_ffn16.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
+# The shipped library: ONE kernel per layer, no run-time kernel selection (include/sship.h, "Environment").
+SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_pp.hip", "conv_pp128.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
+# Developer build (lib/variants/dev.so, -DSSHIP_DEV_SWITCHES=1): the same sources with the A/B switches and phase traces compiled in, plus
+# the rejected kernels they select: the lock-step strip conv (r01), Winograd conv2a/2b (r04: -25 %), the 16-wave FFN (r04: +-0), the
+# LDS-resident-key attention (r05: -8 %).  tests/test_gpu_alt_paths.py and scripts/dev/* load it through SUPERSLAM_HIP_LIBRARY.
+DEV_SOURCES = SOURCES + ["conv_strip.hip", "conv_wino.hip", "lg_ffn16.hip", "lg_attn_res.hip"]
+DEV_FLAGS = ["-DSSHIP_DEV_SWITCHES=1"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 # per-file flags.  -fno-honor-nans: under IEEE NaN semantics every fmaxf() operand that comes out of an MFMA is
@@ -63,6 +69,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_dev(force: bool = False) -> str:
+    """lib/variants/dev.so, rebuilt when a source is newer (the A/B tests and scripts load it)."""
+    out = os.path.join(LIBDIR, "variants", "dev.so")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "sship.h"), os.path.abspath(__file__)]
+    if force or not os.path.exists(out) or os.path.getmtime(out) < _newest(deps):
+        build_variant("dev", DEV_FLAGS)
+    return out
+
+
 def build_variant(name: str, extra_flags) -> str:
     """Developer A/B builds: same sources + extra -D flags -> lib/variants/<name>.so (load via SUPERSLAM_HIP_LIBRARY)."""
     vdir = os.path.join(LIBDIR, "variants")
@@ -79,14 +94,18 @@ def build_variant(name: str, extra_flags) -> str:
             raise RuntimeError(r.stdout + r.stderr)
         return obj
 
+    srcs = DEV_SOURCES if "-DSSHIP_DEV_SWITCHES=1" in extra_flags else SOURCES
     with ThreadPoolExecutor(max_workers=6) as ex:
-        objs = list(ex.map(one, SOURCES))
+        objs = list(ex.map(one, srcs))
     out = os.path.join(vdir, name + ".so")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"], check=True)
     return out
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--dev":
+        print(build_dev(force="--force" in sys.argv))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":
         print(build_variant(sys.argv[2], sys.argv[3:]))
         sys.exit(0)

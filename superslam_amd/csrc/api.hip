@@ -294,7 +294,7 @@ static std::vector<_Float16> pack_conv(const float* w, int cout, int cin, int ks
 }
 // Winograd F(2x2, 3x3) weights of a 64 -> 64 layer for conv_wino.hip: U_p = (G g G^T)[xi][nu], p = 4 xi + nu, computed in fp32 and
 // rounded to fp16, packed as MFMA A fragments [p 16][chunk 4][m 2][lane 64][8]: cout = 32 m + (lane & 31), cin = 16 chunk + 8 (lane >> 5) + e
-static int upload_wino(const float* w, ConvW& out) {
+[[maybe_unused]] static int upload_wino(const float* w, ConvW& out) {
   static const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
   std::vector<_Float16> pk((size_t)16 * 4 * 2 * 512);
   for (int co = 0; co < 64; ++co)
@@ -596,7 +596,8 @@ struct sship_sp {
   // activations (channels-last fp16), sized for (B, H, W)
   int wsB = 0, wsH = 0, wsW = 0;
   DevBuf img, a1a, a1b, a2a, a2b, a3a, a3b, a4a, a4b, aPa, aDa, draw, logits, cand, cand_count;
-  const void* cand_zero_ptr = nullptr; int cand_zero_n = 0;  // cand_count[0 .. cand_zero_n) of this allocation are known to be zero (sp_select)
+  const void* cand_zero_ptr = nullptr; int cand_zero_n = 0;  // cand_count[0 .. cand_zero_n) of this allocation are known to be zero (sp_select) ...
+  hipStream_t cand_zero_stream = nullptr;                      // ... for work ordered after the last k_topk on THIS stream
   DevBuf kp, cell_h, cell_w, n_dev, desc_stage, gray_in;
   PinBuf h_kp, h_n, h_img;
   int cap = 0;
@@ -657,22 +658,26 @@ static int sp_ensure(sship_sp* sp, int B, int H, int W) {
 
 // 3x3 conv kernel selection.  Default: the ping-pong kernel (conv_pp.hip) for every layer; SUPERSLAM_HIP_CONV=strip
 // runs the lock-step strip kernel instead (conv_strip.hip, kept for A/B runs: profiles/r01_pp_vs_strip.txt).
-static int conv_mode() {  // 1 ping-pong (default), 2 strip
+static int conv_mode() {  // 1 ping-pong (default), 2 strip (developer build only)
   static const int v = [] {
-    const char* e = getenv("SUPERSLAM_HIP_CONV");
-    return (e && std::string(e) == "strip") ? 2 : 1;
+    const char* e = dev_env("SUPERSLAM_HIP_CONV");
+    return (SSHIP_DEV_SWITCHES && e && std::string(e) == "strip") ? 2 : 1;
   }();
   return v;
 }
 static hipError_t conv3(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s) {
+#if SSHIP_DEV_SWITCHES
   // SUPERSLAM_HIP_CONV64=wino: conv2a / conv2b as Winograd F(2x2, 3x3) (conv_wino.hip; A/B)
-  static const bool wino = [] { const char* e = getenv("SUPERSLAM_HIP_CONV64"); return e && std::string(e) == "wino"; }();
+  static const bool wino = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV64"); return e && std::string(e) == "wino"; }();
   if (wino && w.w_wino && sp_conv3x3_wino_fits(H, W, w.cin, w.cout)) return sp_conv3x3_wino(w.w_wino, w.bias, in, out, B, H, W, pool, s);
   return conv_mode() == 1 ? sp_conv3x3_pp(w, in, out, B, H, W, pool, s) : sp_conv3x3_strip(w, in, out, B, H, W, pool, s);
+#else
+  return sp_conv3x3_pp(w, in, out, B, H, W, pool, s);
+#endif
 }
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s);
 static bool desc_dense_mode() {
-  static const bool v = [] { const char* e = getenv("SUPERSLAM_HIP_DESC"); return e && std::string(e) == "dense"; }();
+  static const bool v = [] { const char* e = dev_env("SUPERSLAM_HIP_DESC"); return e && std::string(e) == "dense"; }();
   return v;
 }
 // descriptor rows of the selected keypoints of `B` images (cells / counts at the given pointers)
@@ -728,8 +733,11 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
   sp_shapes(H, W, H2, W2, H4, W4, Hc, Wc);
   // The candidate counters are zeroed by k_topk once it has read them (a 5-us memset launch per call in latency mode otherwise);
   // a memset is needed only for a fresh / regrown buffer or after a call that did not get as far as its k_topk launch.
-  if (sp->cand_zero_ptr != sp->cand_count.p || sp->cand_zero_n < B) SSHIP_HIP_CHECK(hipMemsetAsync(sp->cand_count.p, 0, (size_t)B * 4, s));
-  sp->cand_zero_ptr = sp->cand_count.p; sp->cand_zero_n = 0;
+  // the counters are zero for THIS call only if the k_topk that zeroed them ran on the same stream (a call on another stream is not
+  // ordered behind it: it clears its own, as every call did before the reset moved into k_topk)
+  if (sp->cand_zero_ptr != sp->cand_count.p || sp->cand_zero_n < B || sp->cand_zero_stream != s)
+    SSHIP_HIP_CHECK(hipMemsetAsync(sp->cand_count.p, 0, (size_t)B * 4, s));
+  sp->cand_zero_ptr = sp->cand_count.p; sp->cand_zero_n = 0; sp->cand_zero_stream = s;
   NmsArgs a{};
   a.logits = sp->logits.as<float>(); a.ls = kLogitStride; a.B = B; a.H = Hc * 8; a.W = Wc * 8;
   a.radius = sp->cfg.nms_radius; a.thr_f = sp->thr_f; a.border = sp->cfg.remove_borders;
@@ -752,8 +760,10 @@ static int sp_select(sship_sp* sp, int B, int H, int W, float* scores_out, float
 }
 
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s) {
-  return conv_mode() != 2 ? sp_conv1ab_pp(sp->c1b, sp->w1a_fragb, sp->b1a, img, out, B, H, W, s)
-                          : sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, img, out, B, H, W, s);
+#if SSHIP_DEV_SWITCHES
+  if (conv_mode() == 2) return sp_conv1ab_fused(sp->c1b, sp->w1a_frag, sp->b1a, img, out, B, H, W, s);
+#endif
+  return sp_conv1ab_pp(sp->c1b, sp->w1a_fragb, sp->b1a, img, out, B, H, W, s);
 }
 
 extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
@@ -787,8 +797,10 @@ extern "C" int sship_sp_create(const sship_sp_config* cfg, sship_sp** out) {
     // (conv_pp.hip), convDa keeps the k order the sparse descriptor head shares
     if (l.ks == 3 && std::string(l.name) != "convDa" && std::string(l.name) != "conv1b")
       if (int rc = upload_conv_q(w->data.data(), l.cout, l.cin, *l.dst)) return rc;
+#if SSHIP_DEV_SWITCHES
     if (std::string(l.name) == "conv2a" || std::string(l.name) == "conv2b")
       if (int rc = upload_wino(w->data.data(), *l.dst)) return rc;
+#endif
     if (std::string(l.name) == "convDb")
       if (int rc = upload_conv(w->data.data(), b->data.data(), l.cout, l.cin, 1, 32, sp->cDb32)) return rc;
     if (std::string(l.name) == "convPb") {  // the streaming kernel reads the plain matrix, [80][256] fp16 (sp_convs.hip: k_convpb_stream)
@@ -1559,7 +1571,7 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   lens = lg->lens_c.as<int>();
   lg->last_pairs = pairs;
   // 3 launches per block: [projection fused into the previous FFN's tail] -> attention -> FFN(+ next projection).
-  static const bool igemm_qkv0 = getenv("SUPERSLAM_HIP_LG_QKV0") && std::string(getenv("SUPERSLAM_HIP_LG_QKV0")) == "igemm";  // A/B
+  static const bool igemm_qkv0 = dev_env("SUPERSLAM_HIP_LG_QKV0") && std::string(dev_env("SUPERSLAM_HIP_LG_QKV0")) == "igemm";  // A/B
   const int n_layers = lg->debug_layers;  // kLgLayers except under sship_lg_debug_set_layers (test-only)
   // the layer stack of pairs [p0, p0 + np) on stream st: every buffer is sequence-major, pairs are independent
   auto layers = [&](int p0, int np, hipStream_t st, bool shared_gpu) -> int {
@@ -1573,8 +1585,11 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
     auto cross_w = [&](int i, const ConvW** o) { o[0] = &w->ffn0_c[i]; o[1] = &w->ffn3_c[i]; o[2] = i + 1 < kLgLayers ? &w->qkv_t[i + 1] : &w->final_t; };
     const ConvW* pf[3];
     self_w(0, pf);
+#if SSHIP_DEV_SWITCHES
     if (igemm_qkv0) SSHIP_HIP_CHECK(lg_linear_heads(w->qkv[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st));
-    else SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st, pf));
+    else
+#endif
+    SSHIP_HIP_CHECK(launch_lg_proj_heads(w->qkv_t[0], xs, ds, /*rope_segs=*/2, /*t_seg=*/2, rs, qs, ks, vs, st, pf));
     for (int i = 0; i < n_layers; ++i) {
       // SelfBlock (both images of every pair in one launch); its FFN also emits CrossBlock's [to_qk | to_v]
       launch_lg_attention(qs, ks, vs, ls, ds, false, cs, st, shared_gpu);
@@ -1600,7 +1615,7 @@ static int lg_forward(sship_lg* lg, const float* kp, int kp_stride, int kp_seq_s
   // runs at 37 % occupancy); a second, independent stream of the same kernels fills those tails, and an attention workgroup
   // (70 KB LDS, transcendental-bound) can share a CU with an FFN workgroup (79 KB, matrix-bound) of the other half.
   // Only when each half still qualifies for the throughput kernels; SUPERSLAM_HIP_LG_SPLIT=1 turns it off (A/B runs).
-  static const int split_env = getenv("SUPERSLAM_HIP_LG_SPLIT") ? atoi(getenv("SUPERSLAM_HIP_LG_SPLIT")) : 0;
+  static const int split_env = dev_env("SUPERSLAM_HIP_LG_SPLIT") ? atoi(dev_env("SUPERSLAM_HIP_LG_SPLIT")) : 0;
   int parts = 1;
   if (split_env >= 1 && split_env <= 1 + sship_lg::kAux) parts = std::min(split_env, pairs);  // forced (1 = off)
   else if ((size_t)2 * (pairs / 2) * lg->NP / 64 >= (size_t)2 * cu_count()) parts = 2;

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 namespace sship {
@@ -16,6 +17,20 @@ typedef float f16x_t __attribute__((ext_vector_type(16)));   // 32x32 MFMA accum
 typedef float f4x_t __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
+
+// Developer A/B switches.  The DEFAULT library reads exactly the environment variables documented in include/sship.h ("Environment":
+// SUPERSLAM_HIP_DEVICE, SSHIP_RCCL_LIBRARY) and runs one kernel per layer; every other switch (kernel selection, phase traces) and every
+// rejected kernel exists only in the developer build  `python -m superslam_amd.build --variant dev -DSSHIP_DEV_SWITCHES=1`
+// (superslam_amd/lib/variants/dev.so, loaded with SUPERSLAM_HIP_LIBRARY by tests/test_gpu_alt_paths.py and scripts/dev/*): there
+// dev_env() is getenv(), here it is a constant null and the branches behind it fold away.
+#ifndef SSHIP_DEV_SWITCHES
+#define SSHIP_DEV_SWITCHES 0
+#endif
+#if SSHIP_DEV_SWITCHES
+inline const char* dev_env(const char* name) { return ::getenv(name); }
+#else
+constexpr const char* dev_env(const char*) { return nullptr; }
+#endif
 
 // Thread-local last error + status plumbing (host side).
 void set_error(const std::string& msg);

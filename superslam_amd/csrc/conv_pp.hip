@@ -535,7 +535,7 @@ static hipError_t launch_pp(const PpArgs& a_in, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;  // every workgroup should feed both of its wave groups
   if (gx < 1) gx = 1;
-  static const bool trace_on = SSHIP_PP_TRACE_BUILD && getenv("SSHIP_PP_TRACE") != nullptr;
+  static const bool trace_on = SSHIP_PP_TRACE_BUILD && dev_env("SSHIP_PP_TRACE") != nullptr;
   static unsigned long long* tbuf = nullptr;
   if (trace_on) {
     if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 2 * 10 * 8);
@@ -568,13 +568,13 @@ hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int 
   // resident.  Measured at 128 images: conv2a 1 115 -> 1 170 us, conv2b 965 -> 954, conv3a 531 -> 565
   // (profiles/r03_n_conv128_16row_tiles_lds_dma.txt) - with the whole weight set in LDS this file's kernel has no weight DMA to
   // save and its two-stage register staging hides the HBM latency better than a DMA that must land within one half-step.
-  static const bool dma64 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV64"); return e && std::string(e) == "dma"; }();
+  static const bool dma64 = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV64"); return e && std::string(e) == "dma"; }();
   if (w.cin == 64 && w.w_q && dma64 && sp_conv3x3_pp128_fits(B, H, W, 64)) return sp_conv3x3_pp128(w, in, out, B, H, W, pool, s);
   if (w.cin == 64 && w.ct == 64) return pool ? launch_pp<64, 64, true, false>(a, s) : launch_pp<64, 64, false, false>(a, s);
   // 128 input channels: the 64-row-tile kernel over 32-channel chunks (conv_pp128.hip) when the layer carries that packing;
   // SUPERSLAM_HIP_CONV128=ct32 keeps the 32-row-tile kernel of this file (A/B runs)
   // (any other value, e.g. th16 / th8, switches the latency-mode choice below off)
-  static const std::string c128 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV128"); return std::string(e ? e : ""); }();
+  static const std::string c128 = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV128"); return std::string(e ? e : ""); }();
   static const bool ct32 = c128 == "ct32";
   // Latency mode (a frame or two per call): the 16 x 32-pixel tiles of conv_pp128.hip give conv4a at 2 x 47 x 172 cells 36 tiles = 18 x 2
   // workgroups on 256 CUs, each running its two tiles' 2 x 4 x 144 MFMAs per wave back to back.  This file's kernel has 8-row tiles and

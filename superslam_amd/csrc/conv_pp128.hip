@@ -373,7 +373,7 @@ static hipError_t launch_pp128(const Pp128Args& a, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;
   if (gx < 1) gx = 1;
-  static const bool trace_on = SSHIP_PP_TRACE_BUILD && getenv("SSHIP_PP_TRACE") != nullptr;
+  static const bool trace_on = SSHIP_PP_TRACE_BUILD && dev_env("SSHIP_PP_TRACE") != nullptr;
   static unsigned long long* tbuf = nullptr;
   Pp128Args b = a;
   if (trace_on) {
@@ -845,7 +845,7 @@ static hipError_t launch_pp128w(const Pp128Args& a, hipStream_t s) {
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr_rc != hipSuccess) return attr_rc;
   const int ncb = a.cout / 64;
-  static const bool pairs_env = !(getenv("SUPERSLAM_HIP_CONV128_PAIRS") && atoi(getenv("SUPERSLAM_HIP_CONV128_PAIRS")) == 0);
+  static const bool pairs_env = !(dev_env("SUPERSLAM_HIP_CONV128_PAIRS") && atoi(dev_env("SUPERSLAM_HIP_CONV128_PAIRS")) == 0);
   const bool pairs = pairs_env && pp128w_pairs_shape(POOL, a.B, a.W);
   const int tiles_x = (a.W + Q_TW - 1) / Q_TW;
   const int ntiles = (pairs ? a.B / 2 * (2 * (tiles_x - 1) + 1) : a.B * tiles_x) * ((a.H + R_TH - 1) / R_TH);  // as the kernel counts them
@@ -853,7 +853,7 @@ static hipError_t launch_pp128w(const Pp128Args& a, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx * 2 > ntiles) gx = (ntiles + 1) / 2;
   if (gx < 1) gx = 1;
-  static const bool trace_on = SSHIP_PP_TRACE_BUILD && getenv("SSHIP_PP_TRACE") != nullptr;
+  static const bool trace_on = SSHIP_PP_TRACE_BUILD && dev_env("SSHIP_PP_TRACE") != nullptr;
   static unsigned long long* tbuf = nullptr;
   Pp128Args b = a;
   b.pairs_on = pairs_env ? 1 : 0;
@@ -889,7 +889,7 @@ hipError_t sp_conv3x3_pp128(const ConvW& w, const _Float16* in, _Float16* out, i
   a.in = in; a.wpack = w.w_q; a.bias = w.bias; a.out = out; a.B = B; a.H = H; a.W = W; a.cout = w.cout;
   if (w.cin == 64) return pool ? launch_pp128w<true, 2>(a, s) : launch_pp128w<false, 2>(a, s);
   // SUPERSLAM_HIP_CONV128=th8 keeps the 8-row-tile kernel with register staging (A/B runs)
-  static const bool th8 = [] { const char* e = getenv("SUPERSLAM_HIP_CONV128"); return e && std::string(e) == "th8"; }();
+  static const bool th8 = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV128"); return e && std::string(e) == "th8"; }();
   if (th8) return pool ? launch_pp128<true>(a, s) : launch_pp128<false>(a, s);
   return pool ? launch_pp128w<true, 4>(a, s) : launch_pp128w<false, 4>(a, s);
 }

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512) void conv3x3_strip(StripArgs p) {
 template <int CIN, int CT, bool POOL, bool FUSE1A>
 static hipError_t launch_strip(const StripArgs& a_in, hipStream_t s) {
   StripArgs a = a_in;
-  static const int dbg = getenv("SSHIP_STRIP_DBG") ? atoi(getenv("SSHIP_STRIP_DBG")) : 0;
+  static const int dbg = dev_env("SSHIP_STRIP_DBG") ? atoi(dev_env("SSHIP_STRIP_DBG")) : 0;
   a.dbg = dbg;
   constexpr size_t smem = (size_t)(S_IN_HALFS + S_W_HALFS) * 2 + (FUSE1A ? S_PATCH_H * S_PATCH_W * 2 : 0);
   static_assert(smem <= 163840, "LDS budget");

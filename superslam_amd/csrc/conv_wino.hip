@@ -368,7 +368,7 @@ static hipError_t launch_wino(const WinoArgs& a, hipStream_t s) {
   if (attr_rc != hipSuccess) return attr_rc;
   const int ntiles = a.B * ((a.W + W_TW - 1) / W_TW) * ((a.H + W_TH - 1) / W_TH);
   const int gx = ntiles < cu_count() ? ntiles : cu_count();
-  static const bool trace_on = SSHIP_WINO_TRACE_BUILD && getenv("SSHIP_WINO_TRACE") != nullptr;
+  static const bool trace_on = SSHIP_WINO_TRACE_BUILD && dev_env("SSHIP_WINO_TRACE") != nullptr;
   static unsigned long long* tbuf = nullptr;
   WinoArgs b = a;
   if (trace_on) {

@@ -503,7 +503,7 @@ hipError_t launch_lg_ffn16(int tokens, int next_mt, bool heads, hipStream_t s, c
   const int n32 = tokens / 32;
   const int grid = std::min(cu_count(), n32 / 2);
   t.ntiles = n32;
-  static const bool trace_on = getenv("SSHIP_FFN_TRACE") != nullptr;
+  static const bool trace_on = dev_env("SSHIP_FFN_TRACE") != nullptr;
   static unsigned long long* trace_buf = nullptr;
   if (trace_on) {
     const size_t bytes = (size_t)cu_count() * 16 * 16 * 8;

@@ -124,12 +124,14 @@ static IgemmArgs token_args(const ConvW& w, const _Float16* in0, int cs0, const 
   return a;
 }
 
+#if SSHIP_DEV_SWITCHES  // the first Wqkv as a stand-alone implicit GEMM (SUPERSLAM_HIP_LG_QKV0=igemm; the default runs it in the FFN kernel's projection stage)
 hipError_t lg_linear_heads(const ConvW& w, const _Float16* x, LgDims d, int rope_segs, int t_seg, const float* rope,
                            _Float16* q, _Float16* k, _Float16* vt, hipStream_t s) {
   IgemmArgs a = token_args(w, x, 256, nullptr, 0, d);
   a.out0 = q; a.out1 = k; a.out2 = vt; a.aux = rope; a.flags = rope_segs | (t_seg << 4);
   return launch_igemm<1, 256, 128, 4, EpiHeads>(a, w.cout_pad, s);
 }
+#endif
 // ---------------------------------------------------------------------------------------------------
 // Flash-style attention, one wave per 32 queries, head_dim 64.  Self (keys = own sequence) and cross
 // (keys = partner sequence s^1: both directions of CrossBlock in one launch).
@@ -470,9 +472,9 @@ static void launch_attn_v(const _Float16* q, const _Float16* k, const _Float16* 
   constexpr bool kWaveUnits = KS == 1 && SSHIP_ATTN_REGFIN;  // see the kernel: gx = query units per (sequence, head), one per wave
   const int gx = kWaveUnits ? (d.NP / 32 + QT - 1) / QT : (d.NP + QPB - 1) / QPB;
   const size_t nwg = kWaveUnits ? (size_t)gx * d.S : (size_t)gx * 4 * d.S;
-  static const bool trace_on = SSHIP_ATTN_TRACE_BUILD && getenv("SSHIP_ATTN_TRACE") != nullptr;
+  static const bool trace_on = SSHIP_ATTN_TRACE_BUILD && dev_env("SSHIP_ATTN_TRACE") != nullptr;
   if (trace_on) { (void)hipMalloc(&tbuf, nwg * 16 * 8); (void)hipMemsetAsync(tbuf, 0, nwg * 16 * 8, s); }
-  static const bool xcd_off = getenv("SUPERSLAM_HIP_ATTN_XCD") && atoi(getenv("SUPERSLAM_HIP_ATTN_XCD")) == 0;  // A/B: plain id order
+  static const bool xcd_off = dev_env("SUPERSLAM_HIP_ATTN_XCD") && atoi(dev_env("SUPERSLAM_HIP_ATTN_XCD")) == 0;  // A/B: plain id order
   hipLaunchKernelGGL((k_lg_attention<QT, KS, V>), dim3((nwg + 7) / 8 * 8), dim3(256), smem, s, q, k, vt, lens, d.NP,
                      cross ? 1 : 0, ctx, tbuf, gx, xcd_off ? -d.S : d.S);
   if (trace_on) {
@@ -492,7 +494,7 @@ constexpr int kAttnV = 3;
 template <int QT, int KS>
 static void launch_attn(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                         _Float16* ctx, hipStream_t s) {
-  static const int v_env = getenv("SUPERSLAM_HIP_ATTN_V") ? atoi(getenv("SUPERSLAM_HIP_ATTN_V")) : kAttnV;
+  static const int v_env = dev_env("SUPERSLAM_HIP_ATTN_V") ? atoi(dev_env("SUPERSLAM_HIP_ATTN_V")) : kAttnV;
   if (v_env == 3) launch_attn_v<QT, KS, 3>(q, k, vt, lens, d, cross, ctx, s);
   else if (v_env == 2) launch_attn_v<QT, KS, 2>(q, k, vt, lens, d, cross, ctx, s);
   else launch_attn_v<QT, KS, 1>(q, k, vt, lens, d, cross, ctx, s);
@@ -502,15 +504,19 @@ void launch_lg_attention(const _Float16* q, const _Float16* k, const _Float16* v
   // throughput batches: two query tiles per wave (half the K/V fragment traffic) and a 2-way key split; a few pairs only:
   // one tile per wave, 4-way key split, so the launch still has enough workgroups to cover the CUs (latency mode).
   // SUPERSLAM_HIP_ATTN_KS=4 keeps the 4-way split for throughput batches (A/B runs).
-  static const int ks_env = getenv("SUPERSLAM_HIP_ATTN_KS") ? atoi(getenv("SUPERSLAM_HIP_ATTN_KS")) : 0;
+  static const int ks_env = dev_env("SUPERSLAM_HIP_ATTN_KS") ? atoi(dev_env("SUPERSLAM_HIP_ATTN_KS")) : 0;
   // SUPERSLAM_HIP_ATTN_QT=1 (A/B runs): one query tile per wave also for throughput batches - 144-156 VGPRs, three waves per SIMD
   // instead of two (a wave issues one VALU instruction per ~5 clocks, the SIMD retires one per 2: more waves = more VALU issue),
   // at twice the K / V^T fragment traffic per query
-  static const int qt_env = getenv("SUPERSLAM_HIP_ATTN_QT") ? atoi(getenv("SUPERSLAM_HIP_ATTN_QT")) : 0;
-  static const bool stream_env = getenv("SUPERSLAM_HIP_ATTN") && std::string(getenv("SUPERSLAM_HIP_ATTN")) == "stream";  // A/B: the streaming kernel
-  if (!stream_env && d.S * (d.NP / 64) * 4 >= 2 * cu_count() && lg_attention_res_fits(d)) {
+  static const int qt_env = dev_env("SUPERSLAM_HIP_ATTN_QT") ? atoi(dev_env("SUPERSLAM_HIP_ATTN_QT")) : 0;
+#if SSHIP_DEV_SWITCHES  // SUPERSLAM_HIP_ATTN=res: the keys of a (sequence, head) resident in LDS (lg_attn_res.hip; measured slower: profiles/r05_a_*)
+  static const bool res_env = dev_env("SUPERSLAM_HIP_ATTN") && std::string(dev_env("SUPERSLAM_HIP_ATTN")) == "res";
+  if (res_env && d.S * (d.NP / 64) * 4 >= 2 * cu_count() && lg_attention_res_fits(d)) {
     launch_lg_attention_res(q, k, vt, lens, d, cross, ctx, s);
-  } else if (d.S * (d.NP / 64) * 4 >= 2 * cu_count()) {
+    return;
+  }
+#endif
+  if (d.S * (d.NP / 64) * 4 >= 2 * cu_count()) {
     // shared_gpu: another stream runs the other half-batch's kernels next to this launch (lg_forward), so the partly filled last
     // round of a 256-query workgroup (no key split: no LDS merge, the prologue paid once per 19 key tiles) costs nothing:
     // 92 -> 101 us for a launch on its own, but -1.2 % on the two-stream LightGlue call
@@ -1534,7 +1540,7 @@ static hipError_t launch_ffn4(int tokens, hipStream_t s, A... args) {
 // the 4-wave kernel serves throughput batches (at least one 64-token tile per workgroup slot); SUPERSLAM_HIP_FFN=8 keeps
 // the 8-wave kernel everywhere (A/B runs)
 static bool use_ffn4(int tokens) {
-  static const int env = getenv("SUPERSLAM_HIP_FFN") ? atoi(getenv("SUPERSLAM_HIP_FFN")) : 0;
+  static const int env = dev_env("SUPERSLAM_HIP_FFN") ? atoi(dev_env("SUPERSLAM_HIP_FFN")) : 0;
   // k_lg_ffn4 addresses x / q / k / v^T through buffer resources with 32-bit byte offsets (token * 512 B): beyond ~2 GiB of
   // token stream its out-of-range stores would be dropped silently - such launches use the 8-wave kernel (64-bit addresses)
   if ((size_t)tokens * 512 >= 0x7f000000ull) return false;
@@ -1545,11 +1551,9 @@ static bool use_ffn4(int tokens) {
 
 // SUPERSLAM_HIP_FFN=16: the 16-wave kernel of lg_ffn16.hip for every launch it applies to; default: for throughput batches
 // (at least four 32-token N-tiles per CU)
-static bool use_ffn16(int tokens) {
-  static const int env = getenv("SUPERSLAM_HIP_FFN") ? atoi(getenv("SUPERSLAM_HIP_FFN")) : 0;
-  if (env == 16) return true;
-  if (env == 4 || env == 8) return false;
-  return false;   // until measured
+[[maybe_unused]] static bool use_ffn16(int tokens) {
+  static const int env = dev_env("SUPERSLAM_HIP_FFN") ? atoi(dev_env("SUPERSLAM_HIP_FFN")) : 0;
+  return env == 16;   // measured: no gain over k_lg_ffn4 (profiles/r04_b .. r04_e) - never the default
 }
 static bool trace_on_is8() { return false; }
 // SSHIP_FFN_TRACE=1 with the 4-wave kernel: mean shader-clock duration of every phase of a workgroup's second tile
@@ -1582,7 +1586,7 @@ static void ffn4_trace_report(unsigned long long* dev, int nwg, int next_mt, hip
 // the updated tile; heads = true -> EpiHeads (q/k/vt, rope_segs, t_seg), false -> fp16 rows to `out` (+ matchability).
 // Latency mode's weight prefetch (FfnTail::n_main): the packed weights the NEXT FFN launch will stream, when the launch leaves CUs free
 static int ffn_prefetch_setup(FfnTail& t, int n_main, const ConvW* const* pf) {
-  static const bool off = getenv("SUPERSLAM_HIP_LG_PREFETCH") && atoi(getenv("SUPERSLAM_HIP_LG_PREFETCH")) == 0;  // A/B runs
+  static const bool off = dev_env("SUPERSLAM_HIP_LG_PREFETCH") && atoi(dev_env("SUPERSLAM_HIP_LG_PREFETCH")) == 0;  // A/B runs
   constexpr int kPfWg = 64;  // 8 per XCD
   if (off || !pf || n_main + kPfWg > cu_count()) return 0;
   int k = 0;
@@ -1599,17 +1603,17 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
                    float* logsig, hipStream_t s, const ConvW* const* prefetch) {
   const int tokens = d.S * d.NP;
   FfnTail t{};
-  static const int nt_env = getenv("SUPERSLAM_HIP_FFN_NT") ? atoi(getenv("SUPERSLAM_HIP_FFN_NT")) : 0;  // A/B: 1 | 2
+  static const int nt_env = dev_env("SUPERSLAM_HIP_FFN_NT") ? atoi(dev_env("SUPERSLAM_HIP_FFN_NT")) : 0;  // A/B: 1 | 2
   const int nt = nt_env == 1 || nt_env == 2 ? nt_env : (tokens / 64 < cu_count() / 2 ? 1 : 2);  // 32-token N-tiles per workgroup tile
   t.ntiles = tokens / (nt * 32);
-  static const bool trace_on = getenv("SSHIP_FFN_TRACE") != nullptr;
+  static const bool trace_on = dev_env("SSHIP_FFN_TRACE") != nullptr;
   static unsigned long long* trace_buf = nullptr;
   const int trace_wg = t.ntiles < cu_count() ? t.ntiles : cu_count();
   if (trace_on) {
     if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)2 * cu_count() * 8 * 12 * 8);
     (void)hipMemsetAsync(trace_buf, 0, (size_t)2 * cu_count() * 8 * 12 * 8, s);
     t.trace = trace_buf;
-    static const int trace_it = getenv("SSHIP_FFN_TRACE_IT") ? atoi(getenv("SSHIP_FFN_TRACE_IT")) : 1;
+    static const int trace_it = dev_env("SSHIP_FFN_TRACE_IT") ? atoi(dev_env("SSHIP_FFN_TRACE_IT")) : 1;
     t.trace_it = trace_it;
   }
   if (!next) {
@@ -1622,10 +1626,12 @@ void launch_lg_ffn(const ConvW& w0, const ConvW& w3, const float* gamma, const f
   t.proj.flags = rope_segs | (t_seg << 4); t.proj.ostride = 256;
   t.match_w = match_w; t.match_b = match_b; t.logsig = logsig;
   const int mt = next->cout / 256;  // rows per wave / 32: 768 -> 3, 512 -> 2, 256 -> 1
+#if SSHIP_DEV_SWITCHES
   if (use_ffn16(tokens) && ffn16_applicable(tokens, mt, heads)) {
     (void)launch_lg_ffn16(tokens, mt, heads, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
     return;
   }
+#endif
   if (use_ffn4(tokens) && !trace_on_is8()) {
     t.ntiles = tokens / 64;
     if (heads && mt == 3) (void)launch_ffn4<3, true, false>(tokens, s, ctx, w0.w, w0.bias, gamma, beta, w3.w, w3.bias, x, t);
@@ -1693,6 +1699,7 @@ void launch_lg_sim(const _Float16* md, const int* lens, LgDims d, float* sim, hi
   hipLaunchKernelGGL(k_lg_sim, dim3((d.NP + 127) / 128, d.NP / 32, d.S / 2), dim3(256), 0, s, md, lens, d.NP, sim);
 }
 
+#if SSHIP_DEV_SWITCHES  // the four passes over a materialised sim (SUPERSLAM_HIP_LG_ASSIGN=matrix; replaced by k_assign_stream in round 2)
 // workspace per pair (floats): [0,NP) lse_row, [NP,2NP) lse_col, [2NP,3NP) max0, [3NP,4NP) m0 (int), [4NP,5NP) m1 (int)
 __global__ __launch_bounds__(256) void k_assign_row_lse(const float* __restrict__ sim, const int* __restrict__ lens,
                                                         int NP, float* __restrict__ ws) {
@@ -1808,6 +1815,7 @@ __global__ void k_assign_final(const int* __restrict__ lens, int NP, const float
   matches0[(size_t)pair * max_kp + i] = mj;
   mscores0[(size_t)pair * max_kp + i] = ms;
 }
+#endif  // SSHIP_DEV_SWITCHES
 // ---------------------------------------------------------------------------------------------------
 // Assignment without the similarity matrix (round 2): two streaming passes over md, each recomputing the 32 x 32 tiles of
 // sim = md0 md1^T on the matrix cores in BOTH orientations, so that every statistic is lane-local:
@@ -2061,7 +2069,8 @@ __global__ __launch_bounds__(256) void k_assign_mutual(const float* __restrict__
 void launch_lg_assign(const _Float16* md, const float* logsig, const int* lens, LgDims d, float* ws, float* pcol, int max_kp,
                       int32_t* matches0, float* mscores0, float thr, int stage, hipStream_t s) {
   const int P = d.S / 2, NT = d.NP / 32;
-  static const bool legacy = getenv("SUPERSLAM_HIP_LG_ASSIGN") && std::string(getenv("SUPERSLAM_HIP_LG_ASSIGN")) == "matrix";  // A/B
+#if SSHIP_DEV_SWITCHES
+  static const bool legacy = dev_env("SUPERSLAM_HIP_LG_ASSIGN") && std::string(dev_env("SUPERSLAM_HIP_LG_ASSIGN")) == "matrix";  // A/B
   if (legacy && stage == 0) {  // the four passes over a materialised sim (sim lives in pcol's allocation: P * NP * NP floats)
     float* sim = pcol;
     launch_lg_sim(md, lens, d, sim, s);
@@ -2069,7 +2078,11 @@ void launch_lg_assign(const _Float16* md, const float* logsig, const int* lens, 
     hipLaunchKernelGGL(k_assign_col_lse, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, lens, d.NP, ws);
     hipLaunchKernelGGL(k_assign_row_arg, dim3(d.NP / 4, P), dim3(256), 0, s, sim, logsig, lens, d.NP, ws);
     hipLaunchKernelGGL(k_assign_col_arg, dim3((d.NP + 63) / 64, P), dim3(64 * kColRG), 0, s, sim, logsig, lens, d.NP, ws);
-  } else {
+    hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr, matches0, mscores0);
+    return;
+  }
+#endif
+  {
     // partials inside pcol's allocation (P * NP * NP floats): [P][NT][NP][2] column + [P][kAssignCh][NP][2] row partials of PASS 0, then those of PASS 1
     float* prow = pcol + (size_t)P * NT * d.NP * 2;
     float* pcol1 = prow + (size_t)P * kAssignCh * d.NP * 2;
@@ -2080,11 +2093,7 @@ void launch_lg_assign(const _Float16* md, const float* logsig, const int* lens, 
       hipLaunchKernelGGL(k_assign_stream<1>, dim3((NT + 3) / 4, P, kAssignCh), dim3(256), 0, s, md, logsig, lens, d.NP, pcol1, prow1, pcol, prow);
     if (stage == 0)
       hipLaunchKernelGGL(k_assign_mutual, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, pcol1, prow1, lens, d.NP, max_kp, thr, matches0, mscores0);
-    return;
   }
-  if (stage == 0)
-    hipLaunchKernelGGL(k_assign_final, dim3((max_kp + 255) / 256, P), dim3(256), 0, s, lens, d.NP, ws, max_kp, thr,
-                       matches0, mscores0);
 }
 
 }  // namespace sship

@@ -7,9 +7,11 @@
 //
 // RCCL is bound at RUN TIME (dlsym on the process first, then dlopen("librccl.so.1")): a process that already carries an RCCL -
 // a Python host under torch.distributed, whose torch/lib/librccl.so is loaded - must not get a second copy of the library next
-// to it, and single-GPU users of libsuperslam_hip.so need no RCCL at all.
+// to it, and single-GPU users of libsuperslam_hip.so need no RCCL at all.  SSHIP_RCCL_LIBRARY=<path> (include/sship.h, "Environment")
+// names the one library to bind instead.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <mutex>
@@ -42,11 +44,15 @@ Rccl& rccl() {
   static std::once_flag once;
   std::call_once(once, [] {
     void* h = RTLD_DEFAULT;
-    if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+    const char* forced = getenv("SSHIP_RCCL_LIBRARY");
+    if (forced && *forced) {
+      h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) { const char* e = dlerror(); r.why = std::string("RCCL not found (SSHIP_RCCL_LIBRARY=") + forced + "): " + (e ? e : ""); return; }
+    } else if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
       h = nullptr;
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-      if (!h) { r.why = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return; }
+      if (!h) { const char* e = dlerror(); r.why = std::string("RCCL not found (dlopen librccl.so.1): ") + (e ? e : ""); return; }  // dlerror() clears itself: ONE call
     }
     auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) r.why = std::string("RCCL symbol missing: ") + n; return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -105,8 +111,11 @@ extern "C" int sship_comm_create(const void* id_128, int rank, int world, sship_
 extern "C" void sship_comm_destroy(sship_comm* c) {
   if (!c) return;
   if (c->comm && rccl().ok) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     (void)hipSetDevice(c->device);  // the calling thread may be bound elsewhere (handles are used from more than one thread)
     (void)rccl().CommDestroy(c->comm);
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);  // ... and stays bound where it was
   }
   delete c;
 }
@@ -122,7 +131,10 @@ extern "C" int sship_gather_features_rccl(sship_comm* c, const void* desc_local_
   if (!desc_local_dev || !kp_local_dev || !n_local_dev || !desc_all_dev || !kp_all_dev || !n_all_dev)
     return fail(SSHIP_ERR_INVALID, "gather_features_rccl: null buffer");
   Rccl& r = rccl();
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   if (hipSetDevice(c->device) != hipSuccess) return fail(SSHIP_ERR_NO_DEVICE, "gather_features_rccl: cannot bind the communicator's device");
+  struct Rebind { int prev, dev; ~Rebind() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); } } rebind{prev, c->device};  // the caller's device binding survives the call
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t u = (size_t)units_per_rank, k = (size_t)max_keypoints;
   // one grouped step: RCCL fuses the three all-gathers into a single launch / a single pass over the xGMI links

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void k_convpb_stream(const _Float16* __rest
 hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int ostride, int B, int H, int W,
                           hipStream_t s) {
   if (w.cin != 256) return hipErrorInvalidValue;
-  static const bool use_igemm = getenv("SUPERSLAM_HIP_CONVPB") && std::string(getenv("SUPERSLAM_HIP_CONVPB")) == "igemm";  // A/B
+  static const bool use_igemm = dev_env("SUPERSLAM_HIP_CONVPB") && std::string(dev_env("SUPERSLAM_HIP_CONVPB")) == "igemm";  // A/B (developer build)
   if (w.w_q && w.cout == 65 && ostride >= 68 && ostride % 4 == 0 && !use_igemm) {
     const int P = B * H * W;
     int wgs = 2 * cu_count();
@@ -110,9 +110,13 @@ hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int os
     hipLaunchKernelGGL(k_convpb_stream, dim3(wgs), dim3(256), 0, s, in, w.w_q, w.bias, out, P, ostride);
     return hipGetLastError();
   }
+#if SSHIP_DEV_SWITCHES
   IgemmArgs a = conv_args(w, in, B, H, W);
   a.out0 = out; a.ostride = ostride;
   return launch_igemm<1, 256, 96, 4, EpiF32>(a, w.cout_pad, s);  // 65 rows: three M-tiles, not four
+#else
+  return hipErrorInvalidValue;  // one path per layer: the detector's 1x1 is k_convpb_stream (sship_sp_create always uploads its matrix)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

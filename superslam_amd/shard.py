@@ -200,6 +200,14 @@ class RcclComm:
 
         from . import _lib
 
+        # the C ABI takes raw pointers: anything but dense f16 / f32 / i32 device tensors of the documented shapes would gather the wrong bytes
+        if not (desc.is_cuda and kp.is_cuda and n.is_cuda and desc.device == kp.device == n.device):
+            raise ValueError("gather_features: desc, kp and n must be CUDA tensors on one device")
+        if desc.dtype != torch.float16 or kp.dtype != torch.float32 or n.dtype != torch.int32:
+            raise TypeError(f"gather_features: expected f16 / f32 / i32, got {desc.dtype} / {kp.dtype} / {n.dtype}")
+        if desc.dim() != 3 or desc.shape[2] != 256 or tuple(kp.shape) != (desc.shape[0], desc.shape[1], 3) or tuple(n.shape) != (desc.shape[0],):
+            raise ValueError(f"gather_features: shapes {tuple(desc.shape)} / {tuple(kp.shape)} / {tuple(n.shape)} are not [u,K,256] / [u,K,3] / [u]")
+        desc, kp, n = desc.contiguous(), kp.contiguous(), n.contiguous()
         u, K = desc.shape[0], desc.shape[1]
         da = torch.empty((self.world * u, K, 256), dtype=torch.float16, device=desc.device)
         ka = torch.empty((self.world * u, K, 3), dtype=torch.float32, device=desc.device)

@@ -91,6 +91,45 @@ def test_rccl_exchange_entry_points_validate_their_arguments_and_need_no_rccl_at
     assert "rccl" not in needed.lower() and "torch" not in needed.lower(), needed
 
 
+def test_shipped_library_reads_only_the_documented_environment():
+    """one kernel per layer in the shipped library.  The only environment variable NAMES inside libsuperslam_hip.so
+    are the two include/sship.h documents; every A/B switch and the kernels it selected live in lib/variants/dev.so."""
+    from superslam_amd import _lib, build
+
+    blob = open(os.path.join(ROOT, "superslam_amd", "lib", "libsuperslam_hip.so"), "rb").read()
+    names = set(re.findall(rb"(?:SUPERSLAM_[A-Z0-9_]{3,}|SSHIP_[A-Z0-9_]{3,})", blob))
+    names = {n.decode() for n in names if not n.startswith(b"SSHIP_ERR") and not n.startswith(b"SSHIP_HIP_CHECK")}
+    assert names == {"SUPERSLAM_HIP_DEVICE", "SSHIP_RCCL_LIBRARY"}, names
+    hdr = open(os.path.join(ROOT, "include", "sship.h")).read()
+    assert "SUPERSLAM_HIP_DEVICE" in hdr and "SSHIP_RCCL_LIBRARY" in hdr
+    for rejected in ("conv_strip.hip", "conv_wino.hip", "lg_ffn16.hip", "lg_attn_res.hip"):
+        assert rejected not in build.SOURCES and rejected in build.DEV_SOURCES
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    for k in ("conv_wino", "k_lg_ffn16", "k_assign_row_lse", "attention_res"):
+        assert k not in syms, k
+
+
+def test_rccl_missing_is_an_error_code_not_a_crash():
+    """with no RCCL to bind, sship_comm_unique_id / sship_comm_create with VALID arguments return
+    SSHIP_ERR_NO_DEVICE and a message (the old code called dlerror() twice and built a std::string from NULL).  A fresh process:
+    the binding is resolved once per process; SSHIP_RCCL_LIBRARY names the one library to try (include/sship.h, Environment)."""
+    code = (
+        "import ctypes as C\n"
+        "from superslam_amd import _lib\n"
+        "lib = _lib.lib()\n"
+        "buf = C.create_string_buffer(128)\n"
+        "rc = lib.sship_comm_unique_id(buf)\n"
+        "assert rc == _lib.ERR_NO_DEVICE, rc\n"
+        "msg = lib.sship_last_error()\n"
+        "assert b'RCCL not found' in msg and b'/nonexistent/librccl.so' in msg, msg\n"
+        "h = C.c_void_p()\n"
+        "assert lib.sship_comm_create(buf, 0, 1, C.byref(h)) == _lib.ERR_NO_DEVICE\n"
+        "print('ok')\n")
+    env = dict(os.environ, SSHIP_RCCL_LIBRARY="/nonexistent/librccl.so", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_single_collective_record_packing_round_trips():
     """all_gather_features sends ONE byte record per unit (descriptor rows | keypoint rows | count, padded to 16 B)."""
     import torch

@@ -1,5 +1,8 @@
-"""GPU: the A/B kernel paths kept behind environment switches still agree with the default path, and the
-measurement probe answers.  The switches are read once per process, so every mode runs in its own interpreter."""
+"""GPU: the A/B kernel paths of the DEVELOPER build still agree with the shipped library's single path, and the measurement probe answers.
+The shipped libsuperslam_hip.so has no kernel-selection switches (include/sship.h, "Environment"); a mode with SUPERSLAM_HIP_* switches runs on
+superslam_amd/lib/variants/dev.so (superslam_amd/build.py: DEV_SOURCES, -DSSHIP_DEV_SWITCHES=1; built by __graft_entry__.build()), loaded
+through SUPERSLAM_HIP_LIBRARY; a mode without switches runs on the shipped library.  The switches are read once per process, so every
+mode runs in its own interpreter."""
 import json
 import os
 import subprocess
@@ -10,6 +13,18 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV_LIB = os.path.join(ROOT, "superslam_amd", "lib", "variants", "dev.so")
+
+
+def _env(mode_env):
+    """Process environment of one mode: switches select kernels only in the developer build."""
+    env = _env(mode_env)
+    env.pop("SUPERSLAM_HIP_LIBRARY", None)
+    if mode_env:
+        assert os.path.exists(DEV_LIB), "superslam_amd/lib/variants/dev.so is missing: __graft_entry__.build() produces it"
+        env["SUPERSLAM_HIP_LIBRARY"] = DEV_LIB
+    return env
+
 
 _WORKER = r"""
 import sys, numpy as np
@@ -31,7 +46,7 @@ np.savez({out!r}, **out)
 
 def _run(mode_env, weights_dir, tmp_path, name):
     out = str(tmp_path / (name + ".npz"))
-    env = dict(os.environ, **mode_env)
+    env = _env(mode_env)
     code = _WORKER.format(root=ROOT, sp_path=weights_dir["sp_path"], out=out)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -139,12 +154,29 @@ def test_two_stream_lightglue_is_bit_identical_to_one_stream(weights_dir, tmp_pa
     for name, env in (("split", {"SUPERSLAM_HIP_ATTN_KS": "2"}), ("nosplit", {"SUPERSLAM_HIP_LG_SPLIT": "1", "SUPERSLAM_HIP_ATTN_KS": "2"})):
         out = str(tmp_path / (name + ".npz"))
         code = _LG_WORKER.format(root=ROOT, lg_path=weights_dir["lg_path"], out=out)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", code], env=_env(env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
     np.testing.assert_array_equal(outs[0]["m"], outs[1]["m"])
     np.testing.assert_array_equal(outs[0]["s"], outs[1]["s"])
     print("two-stream LightGlue: 64 pairs,", int((outs[0]["m"] >= 0).sum()), "matches, identical")
+
+
+def test_resident_key_attention_is_bit_identical_to_the_streaming_kernel(weights_dir, tmp_path):
+    """csrc/lg_attn_res.hip (developer build, SUPERSLAM_HIP_ATTN=res): one workgroup per (sequence, head) with K / V^T filled once into LDS by
+    LDS-DMA.  Same MFMAs on the same fragments in the same key order as the shipped k_lg_attention<2, 1, 3> (the kernel a 64-pair call's
+    two half-batches run): matches and scores of a ragged 64-pair batch are identical bit for bit - and so is a batch whose sequences
+    need the second, single-tile query pass, the staged first sweep and the ragged last key tile (lengths 300 .. 600)."""
+    outs = []
+    for name, env in (("stream", {}), ("res", {"SUPERSLAM_HIP_ATTN": "res"})):
+        out = str(tmp_path / ("attn_" + name + ".npz"))
+        code = _LG_WORKER.format(root=ROOT, lg_path=weights_dir["lg_path"], out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=_env(env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    np.testing.assert_array_equal(outs[0]["m"], outs[1]["m"])
+    np.testing.assert_array_equal(outs[0]["s"], outs[1]["s"])
+    print("resident-key attention: 64 pairs,", int((outs[0]["m"] >= 0).sum()), "matches, identical to the streaming kernel")
 
 
 def test_ffn_kernel_variants_agree(weights_dir, tmp_path, parity_report):
@@ -160,7 +192,7 @@ def test_ffn_kernel_variants_agree(weights_dir, tmp_path, parity_report):
                       ("ffn16", {"SUPERSLAM_HIP_FFN": "16"}), ("noprefetch", {"SUPERSLAM_HIP_LG_PREFETCH": "0"})):
         out = str(tmp_path / ("ffn_" + name + ".npz"))
         code = _LG_WORKER.format(root=ROOT, lg_path=weights_dir["lg_path"], out=out)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", code], env=_env(env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[name] = np.load(out)
     for name in ("ffn8", "ffn8_nt1", "ffn16", "noprefetch"):
@@ -211,7 +243,7 @@ def test_conv_kernels_agree_on_tile_corner_cases(weights_dir, tmp_path):
     for name, env in variants:
         out = str(tmp_path / ("dense_" + name + ".npz"))
         code = _DENSE_WORKER.format(root=ROOT, sp_path=weights_dir["sp_path"], shapes=_DENSE_SHAPES, out=out)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", code], env=_env(env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[name] = np.load(out)
     for (h, w, _) in _DENSE_SHAPES:
@@ -290,7 +322,7 @@ def test_winograd_conv2a_conv2b_layer_parity():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for size in ("64x96", "96x249", "376x1376"):
-        env = dict(os.environ, SUPERSLAM_HIP_CONV64="wino")
+        env = _env({"SUPERSLAM_HIP_CONV64": "wino"})
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "wino_check.py"), size, "2"], capture_output=True, text=True,
                            timeout=600, env=env, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
