@@ -278,6 +278,17 @@ int sship_ep_create(const char* weights_path, int input_w, int input_h, sship_ep
 void sship_ep_destroy(sship_ep* ep);
 int sship_ep_descriptor_dim(const sship_ep* ep);
 int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_out);
+/* EigenPlaces::compute_global_descriptor for the image itself (src/EigenPlaces.cc:147-174 including :123-145): u8 image, 1 channel or
+ * 3 = BGR, row stride in bytes, any size.  The image is uploaded as u8 and preprocessed ON THE DEVICE (fixed-point 8-bit bilinear resize to
+ * input_w x input_h, x 1/255, ImageNet mean / std: bit-identical to sship_ep_preprocess), then the network runs as in sship_ep_infer -
+ * the descriptor equals sship_ep_infer(sship_ep_preprocess(img)) bit for bit.
+ *   sship_ep_infer_u8         host image, host descriptor; synchronous (returns after the handle's stream has drained);
+ *   sship_ep_infer_u8_device  device image, device descriptor [512] f32, asynchronous on `stream` (NULL = legacy default stream).  One
+ *                             call in flight per handle (the activations live in the handle). */
+int sship_ep_infer_u8(sship_ep* ep, const uint8_t* img, int h, int w, int stride, int channels, float* desc_out);
+int sship_ep_infer_u8_device(sship_ep* ep, const uint8_t* img_dev, int h, int w, int stride, int channels, float* desc_out_dev, void* stream);
+/* Measurement hook: `iters` back-to-back sship_ep_infer_u8_device calls on the handle's stream over a resident image; average ms. */
+int sship_ep_bench(sship_ep* ep, const uint8_t* img_dev, int h, int w, int stride, int channels, int iters, float* avg_ms);
 /* EigenPlaces::preprocess (src/EigenPlaces.cc:123-145) on the host, no GPU: u8 image (1 channel or 3 = BGR, row stride in bytes) ->
  * fp32 [3, input_h, input_w]: GRAY2RGB / BGR2RGB, cv::resize INTER_LINEAR (OpenCV's 8-bit fixed-point path), x 1/255,
  * ImageNet mean / std.  Exported so that every binding shares one implementation. */

@@ -23,24 +23,26 @@ namespace superslam_hip {
 // ---- cv::resize(src, dst, Size(out_w, out_h), 0, 0, INTER_LINEAR) for CV_8UC{1,3}: OpenCV's fixed-point bilinear path
 // (imgproc/resize.cpp: coordinate (d + 0.5) * scale - 0.5 in float, 11-bit coefficients saturate_cast<short>(w * 2048),
 // horizontal pass in int, vertical pass (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) ----
+// source indices and 11-bit coefficients of one axis (n_src -> n_dst samples); shared by the host resize below and by the device
+// kernel's tables (csrc/ep_kernels.hip: k_ep_resize_norm) - they depend only on the two sizes
+inline void resize_bilinear_coeffs(int n_dst, int n_src, std::vector<int>& s0, std::vector<int>& s1, std::vector<int>& c0, std::vector<int>& c1) {
+  s0.resize(n_dst); s1.resize(n_dst); c0.resize(n_dst); c1.resize(n_dst);
+  const double scale = static_cast<double>(n_src) / n_dst;
+  for (int d = 0; d < n_dst; ++d) {
+    float f = static_cast<float>((d + 0.5) * scale - 0.5);
+    int s = static_cast<int>(std::floor(f));
+    f -= static_cast<float>(s);
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= n_src - 1) { s = n_src - 1; f = 0.f; }
+    s0[d] = s; s1[d] = std::min(s + 1, n_src - 1);
+    c1[d] = static_cast<int>(std::nearbyint(f * 2048.f));            // saturate_cast<short>: round half to even
+    c0[d] = static_cast<int>(std::nearbyint((1.f - f) * 2048.f));
+  }
+}
 inline void resize_bilinear_u8(const uint8_t* src, int h, int w, int stride, int ch, int out_h, int out_w, uint8_t* dst) {
-  auto coeffs = [](int n_dst, int n_src, std::vector<int>& s0, std::vector<int>& s1, std::vector<int>& c0, std::vector<int>& c1) {
-    s0.resize(n_dst); s1.resize(n_dst); c0.resize(n_dst); c1.resize(n_dst);
-    const double scale = static_cast<double>(n_src) / n_dst;
-    for (int d = 0; d < n_dst; ++d) {
-      float f = static_cast<float>((d + 0.5) * scale - 0.5);
-      int s = static_cast<int>(std::floor(f));
-      f -= static_cast<float>(s);
-      if (s < 0) { s = 0; f = 0.f; }
-      if (s >= n_src - 1) { s = n_src - 1; f = 0.f; }
-      s0[d] = s; s1[d] = std::min(s + 1, n_src - 1);
-      c1[d] = static_cast<int>(std::nearbyint(f * 2048.f));            // saturate_cast<short>: round half to even
-      c0[d] = static_cast<int>(std::nearbyint((1.f - f) * 2048.f));
-    }
-  };
   std::vector<int> sx, sx1, ax0, ax1, sy, sy1, by0, by1;
-  coeffs(out_w, w, sx, sx1, ax0, ax1);
-  coeffs(out_h, h, sy, sy1, by0, by1);
+  resize_bilinear_coeffs(out_w, w, sx, sx1, ax0, ax1);
+  resize_bilinear_coeffs(out_h, h, sy, sy1, by0, by1);
   std::vector<int> r0(static_cast<size_t>(out_w) * ch), r1(r0.size());
   auto hrow = [&](int y, std::vector<int>& row) {
     const uint8_t* p = src + static_cast<size_t>(y) * stride;
@@ -91,10 +93,11 @@ public:
   }
   GlobalDescriptor compute_global_descriptor(const Image& image) {
     if (!ep_) return GlobalDescriptor();  // `if (!context_) return cv::Mat();`
-    std::vector<float> chw(static_cast<size_t>(3) * input_height_ * input_width_);
-    eigenplaces_preprocess(image, input_width_, input_height_, chw.data());
+    // preprocessing (src/EigenPlaces.cc:123-145) runs on the device: the u8 image goes up (0.5 MB instead of 3 MB of fp32), the fixed-point
+    // resize + normalisation is a kernel (bit-identical to eigenplaces_preprocess above, which stays as the host form the tests compare with)
     GlobalDescriptor d(static_cast<size_t>(sship_ep_descriptor_dim(ep_)));
-    if (sship_ep_infer(ep_, chw.data(), d.data()) != SSHIP_OK) { last_error_ = sship_last_error(); return GlobalDescriptor(); }
+    const int stride = image.stride ? image.stride : image.cols * image.channels;
+    if (sship_ep_infer_u8(ep_, image.data, image.rows, image.cols, stride, image.channels, d.data()) != SSHIP_OK) { last_error_ = sship_last_error(); return GlobalDescriptor(); }
     double n = 0.0;  // cv::normalize(desc, desc, 1.0, 0.0, cv::NORM_L2)
     for (float v : d) n += static_cast<double>(v) * v;
     n = std::sqrt(n);

@@ -83,6 +83,9 @@ _SIGS = {
     "sship_ep_descriptor_dim": (ip, [vp]),
     "sship_ep_infer": (ip, [vp, vp, vp]),
     "sship_ep_preprocess": (ip, [vp, ip, ip, ip, ip, ip, ip, vp]),
+    "sship_ep_infer_u8": (ip, [vp, vp, ip, ip, ip, ip, vp]),
+    "sship_ep_infer_u8_device": (ip, [vp, vp, ip, ip, ip, ip, vp, vp]),
+    "sship_ep_bench": (ip, [vp, vp, ip, ip, ip, ip, ip, C.POINTER(C.c_float)]),
     "sship_desc_to_host": (ip, [vp, ip, ip, vp]),
     "sship_frontend_batch_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp, vp]),
     "sship_sp_bench_layer": (ip, [vp, ip, ip, ip, ip, ip, C.POINTER(fp), C.POINTER(C.c_double)]),

@@ -1806,6 +1806,9 @@ struct sship_ep {
   float gem_p = 3.f;
   DevBuf d_in, patches, act[4], d_out;
   PinBuf h_out;
+  DevBuf d_img, d_tab;      // u8 entry points: the uploaded image and the resize tables of (tab_h, tab_w) -> (in_h, in_w)
+  PinBuf h_img;
+  int tab_h = 0, tab_w = 0;
 };
 extern "C" void sship_ep_destroy(sship_ep* ep) {
   bind_thread();
@@ -1891,12 +1894,9 @@ extern "C" int sship_ep_preprocess(const uint8_t* img, int h, int w, int stride,
   superslam_hip::eigenplaces_preprocess(superslam_hip::Image{img, h, w, channels, stride}, input_w, input_h, chw_out);
   return SSHIP_OK;
 }
-extern "C" int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_out) {
-  bind_thread();
-  if (!ep || !chw_host || !desc_out) return fail(SSHIP_ERR_INVALID, "ep_infer: null argument");
-  hipStream_t s = ep->stream;
+// the network from the preprocessed fp32 [3, H, W] tensor in d_in to the descriptor in `desc_dev`, on stream s
+static int ep_network(sship_ep* ep, float* desc_dev, hipStream_t s) {
   const int H = ep->in_h, W = ep->in_w;
-  SSHIP_HIP_CHECK(hipMemcpyAsync(ep->d_in.p, chw_host, (size_t)3 * H * W * 4, hipMemcpyHostToDevice, s));
   int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
   launch_ep_im2col(ep->d_in.as<float>(), H, W, h, w, ep->patches.as<_Float16>(), s);
   _Float16* a[4] = {ep->act[0].as<_Float16>(), ep->act[1].as<_Float16>(), ep->act[2].as<_Float16>(), ep->act[3].as<_Float16>()};
@@ -1919,11 +1919,83 @@ extern "C" int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_o
     SSHIP_HIP_CHECK(ep_conv(blk.c2, a[f[0]], a[f[2]], res, ho, wo, true, false, s));
     cur = f[2]; h = ho; w = wo;
   }
-  launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, ep->d_out.as<float>(), s);
+  launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, desc_dev, s);
   SSHIP_HIP_CHECK(hipGetLastError());
+  return SSHIP_OK;
+}
+extern "C" int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_out) {
+  bind_thread();
+  if (!ep || !chw_host || !desc_out) return fail(SSHIP_ERR_INVALID, "ep_infer: null argument");
+  hipStream_t s = ep->stream;
+  SSHIP_HIP_CHECK(hipMemcpyAsync(ep->d_in.p, chw_host, (size_t)3 * ep->in_h * ep->in_w * 4, hipMemcpyHostToDevice, s));
+  if (int rc = ep_network(ep, ep->d_out.as<float>(), s)) return rc;
   SSHIP_HIP_CHECK(hipMemcpyAsync(ep->h_out.p, ep->d_out.p, 512 * 4, hipMemcpyDeviceToHost, s));
   SSHIP_HIP_CHECK(hipStreamSynchronize(s));
   memcpy(desc_out, ep->h_out.p, 512 * 4);
+  return SSHIP_OK;
+}
+// resize tables of (h, w) -> (in_h, in_w): rebuilt only when the source size changes (a dataset has one)
+static int ep_tables(sship_ep* ep, int h, int w) {
+  if (ep->tab_h == h && ep->tab_w == w) return SSHIP_OK;
+  std::vector<int> t[8];
+  superslam_hip::resize_bilinear_coeffs(ep->in_w, w, t[0], t[1], t[2], t[3]);
+  superslam_hip::resize_bilinear_coeffs(ep->in_h, h, t[4], t[5], t[6], t[7]);
+  std::vector<int> flat;
+  for (auto& v : t) flat.insert(flat.end(), v.begin(), v.end());
+  SSHIP_HIP_CHECK(ep->d_tab.ensure(flat.size() * 4));
+  SSHIP_HIP_CHECK(hipDeviceSynchronize());  // a call still reading the old tables (another stream) finishes first; rare path
+  SSHIP_HIP_CHECK(hipMemcpy(ep->d_tab.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+  ep->tab_h = h; ep->tab_w = w;
+  return SSHIP_OK;
+}
+static int ep_check_image(const void* img, int h, int w, int stride, int channels, const char* who) {
+  if (!img || h <= 0 || w <= 0 || (channels != 1 && channels != 3) || stride < w * channels || h > 16384 || w > 16384)
+    return fail(SSHIP_ERR_INVALID, std::string(who) + ": bad image arguments");
+  return SSHIP_OK;
+}
+extern "C" int sship_ep_infer_u8_device(sship_ep* ep, const uint8_t* img_dev, int h, int w, int stride, int channels, float* desc_out_dev,
+                                        void* stream) {
+  bind_thread();
+  if (!ep || !desc_out_dev) return fail(SSHIP_ERR_INVALID, "ep_infer_u8_device: null argument");
+  if (int rc = ep_check_image(img_dev, h, w, stride, channels, "ep_infer_u8_device")) return rc;
+  if (int rc = ep_tables(ep, h, w)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_ep_resize_norm(img_dev, stride, channels, ep->d_tab.as<int>(), ep->in_w, ep->in_h, ep->d_in.as<float>(), s);
+  return ep_network(ep, desc_out_dev, s);
+}
+extern "C" int sship_ep_infer_u8(sship_ep* ep, const uint8_t* img, int h, int w, int stride, int channels, float* desc_out) {
+  bind_thread();
+  if (!ep || !desc_out) return fail(SSHIP_ERR_INVALID, "ep_infer_u8: null argument");
+  if (int rc = ep_check_image(img, h, w, stride, channels, "ep_infer_u8")) return rc;
+  hipStream_t s = ep->stream;
+  const size_t row = (size_t)w * channels, bytes = row * h;
+  SSHIP_HIP_CHECK(ep->h_img.ensure(bytes));
+  SSHIP_HIP_CHECK(ep->d_img.ensure(bytes));
+  for (int y = 0; y < h; ++y) memcpy(ep->h_img.as<uint8_t>() + (size_t)y * row, img + (size_t)y * stride, row);  // pinned, dense rows
+  SSHIP_HIP_CHECK(hipMemcpyAsync(ep->d_img.p, ep->h_img.p, bytes, hipMemcpyHostToDevice, s));
+  if (int rc = sship_ep_infer_u8_device(ep, ep->d_img.as<uint8_t>(), h, w, (int)row, channels, ep->d_out.as<float>(), s)) return rc;
+  SSHIP_HIP_CHECK(hipMemcpyAsync(ep->h_out.p, ep->d_out.p, 512 * 4, hipMemcpyDeviceToHost, s));
+  SSHIP_HIP_CHECK(hipStreamSynchronize(s));
+  memcpy(desc_out, ep->h_out.p, 512 * 4);
+  return SSHIP_OK;
+}
+extern "C" int sship_ep_bench(sship_ep* ep, const uint8_t* img_dev, int h, int w, int stride, int channels, int iters, float* avg_ms) {
+  bind_thread();
+  if (!ep || !avg_ms || iters <= 0) return fail(SSHIP_ERR_INVALID, "ep_bench: bad arguments");
+  hipStream_t s = ep->stream;
+  if (int rc = sship_ep_infer_u8_device(ep, img_dev, h, w, stride, channels, ep->d_out.as<float>(), s)) return rc;  // warm
+  hipEvent_t e0, e1;
+  SSHIP_HIP_CHECK(hipEventCreate(&e0));
+  SSHIP_HIP_CHECK(hipEventCreate(&e1));
+  SSHIP_HIP_CHECK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i)
+    if (int rc = sship_ep_infer_u8_device(ep, img_dev, h, w, stride, channels, ep->d_out.as<float>(), s)) return rc;
+  SSHIP_HIP_CHECK(hipEventRecord(e1, s));
+  SSHIP_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SSHIP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *avg_ms = ms / iters;
   return SSHIP_OK;
 }
 

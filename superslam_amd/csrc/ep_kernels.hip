@@ -70,6 +70,43 @@ hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Flo
   return hipErrorInvalidValue;
 }
 
+// EigenPlaces::preprocess on the device (src/EigenPlaces.cc:123-145): GRAY2RGB / BGR2RGB, cv::resize INTER_LINEAR on 8-bit data, x 1/255,
+// ImageNet mean / std, HWC -> CHW.  OpenCV's 8-bit path is fixed-point and this kernel is its restatement integer for integer
+// (include/superslam_hip/place_recognizer.hpp::resize_bilinear_u8 is the host form the oracle pins): the tables hold, per output column /
+// row, the two source indices and the two 11-bit coefficients (computed on the host, by the same code as the host path - they depend only
+// on the two sizes); a thread does one output pixel: horizontal pass in int, vertical pass
+//   (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, saturate to u8,
+// then the three float operations of the host path in the same order (one multiply, one subtract, one correctly rounded divide: no
+// contraction possible).  Output fp32 CHW, bit-identical to sship_ep_preprocess.
+// tab: [4][out_w] ints (sx, sx1, ax0, ax1) then [4][out_h] (sy, sy1, by0, by1)
+__global__ __launch_bounds__(256) void k_ep_resize_norm(const uint8_t* __restrict__ src, int stride, int ch, const int* __restrict__ tab,
+                                                        int out_w, int out_h, float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= out_w * out_h) return;
+  const int y = idx / out_w, x = idx - y * out_w;
+  const int sx = tab[x], sx1 = tab[out_w + x], ax0 = tab[2 * out_w + x], ax1 = tab[3 * out_w + x];
+  const int* ty = tab + 4 * out_w;
+  const int sy = ty[y], sy1 = ty[out_h + y], by0 = ty[2 * out_h + y], by1 = ty[3 * out_h + y];
+  const uint8_t* p0 = src + (size_t)sy * stride;
+  const uint8_t* p1 = src + (size_t)sy1 * stride;
+  const float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 0.225f};
+  const size_t hw = (size_t)out_w * out_h;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sc = ch == 1 ? 0 : 2 - c;  // GRAY2RGB replicates, BGR2RGB swaps (per-channel resize commutes with both)
+    const int r0 = p0[sx * ch + sc] * ax0 + p0[sx1 * ch + sc] * ax1;
+    const int r1 = p1[sx * ch + sc] * ax0 + p1[sx1 * ch + sc] * ax1;
+    int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : v > 255 ? 255 : v;
+    const float f = (float)v * (1.0f / 255.0f);
+    out[c * hw + idx] = (f - kMean[c]) / kStd[c];
+  }
+}
+void launch_ep_resize_norm(const uint8_t* src, int stride, int ch, const int* tab, int out_w, int out_h, float* out, hipStream_t s) {
+  const int n = out_w * out_h;
+  hipLaunchKernelGGL(k_ep_resize_norm, dim3((n + 255) / 256), dim3(256), 0, s, src, stride, ch, tab, out_w, out_h, out);
+}
+
 // stem im2col: fp32 CHW [3][H][W] -> fp16 rows [Ho*Wo][192], k = c*49 + ky*7 + kx (PyTorch weight order), zero padded
 __global__ __launch_bounds__(256) void k_ep_im2col(const float* __restrict__ x, int H, int W, int Ho, int Wo, _Float16* __restrict__ out) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // one thread per (pixel, 8-wide k group): 24 groups per pixel

@@ -5,8 +5,8 @@
 Retrieval (superslam::CosineDescriptorIndex / TemporalConsistencyVoter, src/PlaceRecognizer.cc) is the reference's own GPU-free control
 plane and is not restated in this package (the tests' restatement: oracle/eigenplaces_ref.py).
 `engine_file` is the safetensors state dict utils/convert_eigenplaces_to_onnx.py:99 saves (the .engine's replacement).
-Preprocessing (src/EigenPlaces.cc:123-145) runs on the host, as in the reference, through the library's own implementation
-(sship_ep_preprocess); the network runs on the GPU (sship_ep_infer)."""
+The u8 image is uploaded and preprocessed on the device (sship_ep_infer_u8: fixed-point 8-bit bilinear resize + normalisation, bit-identical
+to the host form sship_ep_preprocess of src/EigenPlaces.cc:123-145); `preprocess` below exposes the host form for the tests."""
 from __future__ import annotations
 
 import ctypes as C
@@ -60,9 +60,11 @@ class EigenPlaces:
     def compute_global_descriptor(self, image: np.ndarray) -> np.ndarray:
         if self._h is None:
             return np.zeros(0, np.float32)
-        x = preprocess(image, self.input_width, self.input_height)
+        img = np.ascontiguousarray(image, np.uint8)
+        h, w = img.shape[0], img.shape[1]
+        ch = 1 if img.ndim == 2 else img.shape[2]
         d = np.zeros(512, np.float32)
-        rc = _lib.lib().sship_ep_infer(self._h, x.ctypes.data, d.ctypes.data)
+        rc = _lib.lib().sship_ep_infer_u8(self._h, img.ctypes.data, h, w, w * ch, ch, d.ctypes.data)
         if rc != _lib.OK:
             self.last_error = (_lib.lib().sship_last_error() or b"").decode()
             return np.zeros(0, np.float32)
