@@ -183,6 +183,59 @@ def self_check(torch, np, fe, chunk, stream, wdir, max_kp):
     return res
 
 
+def scale_extras(torch, dist, rank, world, backend, dt_own, pairs_per_rank):
+    """N > 1 only, every rank calls it (after the timed region): what ONE multi-GPU lease should answer besides the curve -
+      per_rank_pairs_per_s : each rank's own rate over the timed steps (the headline divides by the slowest);
+      exchange             : the one collective of the sharded front-end, sship_gather_features_rccl through the C ABI, at the
+                             two sizes BASELINE.json names: configs[2] (512 frames x 600 keypoints per rank: 157 MB of descriptors per
+                             rank) and configs[4] (one 1024-keypoint frame per rank: 0.5 MB), 2 warm-up + 5 timed calls each, device
+                             events on the launch stream; GB/s = bytes a rank RECEIVES from its world - 1 peers / time, and the gathered
+                             tensor is checked against every rank's own pattern;
+      rccl_world           : the rank count RCCL itself reports for the communicator.
+    Never fails the bench line: an error becomes a string in the record."""
+    res = {"backend": backend}
+    try:
+        own = [None] * world
+        dist.all_gather_object(own, round(pairs_per_rank / dt_own, 2))
+        res["per_rank_pairs_per_s"] = own
+        if backend != "nccl":
+            res["exchange"] = "skipped: RCCL only (this run's collectives go through " + backend + ")"
+            return res
+        from superslam_amd import _lib
+        from superslam_amd.shard import RcclComm
+
+        comm = RcclComm(rank, world)
+        res["rccl_world"] = int(_lib.lib().sship_comm_world(comm._h))
+        ex = {}
+        for name, units, kp in (("configs[2] offline extraction", 512, 600), ("configs[4] camera rig tick", 1, 1024)):
+            desc = torch.full((units, kp, 256), float(rank + 1), dtype=torch.float16, device="cuda")
+            kpt = torch.full((units, kp, 3), float(rank) + 0.5, dtype=torch.float32, device="cuda")
+            n = torch.full((units,), kp - rank, dtype=torch.int32, device="cuda")
+            for _ in range(2):
+                da, ka, na = comm.gather_features(desc, kpt, n)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                da, ka, na = comm.gather_features(desc, kpt, n)
+            e1.record(); e1.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            ok = all(bool((da[r * units:(r + 1) * units] == float(r + 1)).all()) and bool((na[r * units:(r + 1) * units] == kp - r).all())
+                     and bool((ka[r * units:(r + 1) * units] == float(r) + 0.5).all()) for r in range(world))
+            per_rank = units * kp * (512 + 12) + units * 4
+            t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ex[name] = {"bytes_per_rank": per_rank, "ms": round(float(t.item()), 4), "gathered_equals_ranks_patterns": ok,
+                        "ingest_gb_per_s_per_rank": round(per_rank * (world - 1) / (float(t.item()) * 1e-3) / 1e9, 2),
+                        "aggregate_gb_per_s": round(per_rank * (world - 1) * world / (float(t.item()) * 1e-3) / 1e9, 2)}
+            del desc, kpt, n, da, ka, na
+        res["exchange"] = ex
+        comm.close()
+    except Exception as e:  # noqa: BLE001 - the curve must survive a failing extra
+        res["error"] = f"{type(e).__name__}: {e}"[:400]
+    return res
+
+
 def make_chunks(torch, base, chunks):
     """`chunks` different image sets [2P,H,W] u8 in HBM derived from the P generated pairs: chunk c is the base set rolled
     vertically by 41 c rows (same roll for left and right: the row-band disparities stay a valid stereo geometry) and
@@ -274,8 +327,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_own = dt
     if use_dist:
         dt = all_reduce_max_seconds(dt)   # the slowest rank defines the step time
+    scale = scale_extras(torch, dist, rank, world, backend, dt_own, P * CH * args.steps) if (use_dist and world > 1) else None
 
     n_kp = fe.n.cpu().numpy()
     n_match = int((fe.matches0.cpu().numpy() >= 0).sum())
@@ -305,6 +360,8 @@ def main():
             "executed_tflops": round(value * executed_flops_per_pair(H, W, args.max_kp) / 1e12, 2),
             "executed_frac_of_mfma_peak": round(value * executed_flops_per_pair(H, W, args.max_kp) / 1e12 / MFMA_PEAK_TFLOPS, 4),
         }
+        if scale is not None:
+            out["scale_extras"] = scale
         if not args.headline_only:
             out["self_check"] = self_check(torch, np, fe, chunks[CH - 1], stream, wdir, args.max_kp)
             extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, world, spw, lgw, pairs)
@@ -441,6 +498,24 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
                        "algorithmic_bytes_per_launch": alg_bytes,
                        "sustained_mfma_probe_tflops": probe,
                        "frac_of_sustained_random_probe": round(ach / probe["random_operands"], 4) if probe["random_operands"] > 0 else None}
+    # Every conv row also carries the HBM side of its roofline: algorithmic bytes per launch (activation in + activation out, fp16
+    # channels-last; weights are KBs), achieved GB/s and the bound chosen by FLOP/B against the ridge 2500 TFLOP/s / 8 TB/s = 312.5 FLOP/B.
+    # conv2a (288 FLOP/B) and conv3a / conv4a / conv4b sit AT the ridge: their 0.45 of the MFMA peak is also ~0.5 of the HBM peak
+    #  - `frac` alone reads them as weak matrix kernels, they are nearly saturated memory pipes.
+    RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+    conv_bytes = {"conv1a+conv1b+pool": B * (H * W + H2 * W2 * 64 * 2), "conv2a": B * H2 * W2 * 64 * 2 * 2,
+                  "conv2b+pool": B * (H2 * W2 + H4 * W4) * 64 * 2, "conv3a": B * H4 * W4 * (64 + 128) * 2,
+                  "conv3b+pool": B * (H4 * W4 + Hc * Wc) * 128 * 2, "conv4a": B * Hc * Wc * 128 * 2 * 2, "conv4b": B * Hc * Wc * 128 * 2 * 2,
+                  "convPa": B * Hc * Wc * (128 + 256) * 2}
+
+    def classify(entry, flops, nbytes, ms):
+        inten = flops / nbytes
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        entry.update({"algorithmic_bytes_per_launch": int(nbytes), "flop_per_byte": round(inten, 1), "ridge_flop_per_byte": round(RIDGE, 1),
+                      "achieved_gb_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                      "bound": "mfma" if inten >= 2 * RIDGE else ("hbm" if inten <= RIDGE / 2 else "hbm+mfma (ridge)")})
+
     mfma = []
     names = ["conv1a_standalone_offpath", "conv1a+conv1b+pool", "conv2a", "conv2b+pool", "conv3a", "conv3b+pool", "conv4a", "conv4b",
              "convPa", "convPb", "convDa_dense_offpath", "convDb_dense_offpath"]
@@ -455,6 +530,8 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
                          "gflop_per_launch": round(2.0 * macs / 1e9, 2),
                          "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                          "frac_isolated": round(2.0 * macs / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)})
+            if name in conv_bytes:
+                classify(mfma[-1], 2.0 * macs, conv_bytes[name], ms_in)
     out["layer_ms"] = layer_ms
     # LightGlue stages over the state of the last call (P pairs, S = 2P sequences of n keypoints each; FLOPs for n = max_kp)
     n, S = K, 2 * P
@@ -663,11 +740,25 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     for _ in range(20):
         ep.compute_global_descriptor(pairs[0][0])
     ep_ms = (time.perf_counter() - t3) / 20 * 1e3
-    out["eigenplaces"] = {"ms_per_descriptor": round(ep_ms, 3), "includes": "host preprocess (resize to 512x512, normalise) + H2D + ResNet-18 + GeM + FC + D2H, synchronous",
-                          "gflop": 19.0, "input": [H, W]}
+    ep_dev = C.c_float(0)
+    dimg = torch.from_numpy(pairs[0][0]).cuda()
+    _lib.check(L.sship_ep_bench(ep._h, dimg.data_ptr(), H, W, W, 1, 20, C.byref(ep_dev)))
+    out["eigenplaces"] = {"ms_per_descriptor": round(ep_ms, 3),
+                          "includes": "u8 H2D (0.5 MB, pinned) + device resize to 512x512 / normalise + ResNet-18 + GeM + FC + D2H, synchronous (sship_ep_infer_u8)",
+                          "ms_per_descriptor_device_resident": round(ep_dev.value, 4), "gflop": 19.0, "input": [H, W],
+                          "achieved_tflops_device_resident": round(19.0 / ep_dev.value, 1),
+                          "frac_of_mfma_peak_device_resident": round(19.0 / ep_dev.value / MFMA_PEAK_TFLOPS, 4)}
     ep.close()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], K)
+    # Real checkpoints (SUPERSLAM_SP_WEIGHTS / SUPERSLAM_LG_WEIGHTS set): the dry-run kit's verdict next to the numbers, which are ALL on
+    # seeded weights (a checker leg like cpu_baseline: a child process, after the timed region; absent when the variables are unset)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import real_weights_check
+
+    rw = real_weights_check.verdict_from_env()
+    if rw is not None:
+        out["real_weights"] = rw
 
 
 if __name__ == "__main__":

@@ -19,6 +19,9 @@ happen the first time the real files are on a machine, in the order that localis
 
   python scripts/real_weights_check.py --superpoint ~/weights/superpoint_v1.pth --lightglue ~/weights/superpoint_lightglue.pth
   python scripts/real_weights_check.py --seeded          # the seeded test weights, saved in the published layouts first (CI)
+  SUPERSLAM_SP_WEIGHTS=... SUPERSLAM_LG_WEIGHTS=... python scripts/real_weights_check.py --from-env
+The last form is what `__graft_entry__.smoke()` and `bench.py` run (verdict_from_env below) when the two variables are set: the first
+machine that has the files gets the verdict inside the records the driver already collects, with no extra step.
 
 Exit status 0 = every executed step passed (skipped steps are listed under "skipped"), 1 = a step failed, 2 = bad arguments.
 This is test infrastructure: it imports oracle/ (like tests/ and __graft_entry__.smoke()), the product never imports it.
@@ -112,7 +115,39 @@ def lightglue_headroom(sd, k0, d0, k1, d1):
     return out
 
 
+def verdict_from_env(size="376x1376", max_kp=600, timeout=1500):
+    """SUPERSLAM_SP_WEIGHTS / SUPERSLAM_LG_WEIGHTS set -> the four steps in a child process, condensed verdict dict; unset -> None.
+    (A child process: the kit imports oracle/, its callers keep that out of their own interpreter; a failure becomes {"ok": False, ...}.)"""
+    import subprocess
+
+    sp, lg = os.environ.get("SUPERSLAM_SP_WEIGHTS"), os.environ.get("SUPERSLAM_LG_WEIGHTS")
+    if not sp and not lg:
+        return None
+    if not (sp and lg):
+        return {"ok": False, "error": "set BOTH SUPERSLAM_SP_WEIGHTS and SUPERSLAM_LG_WEIGHTS"}
+    out = os.path.join(tempfile.mkdtemp(prefix="sship_rw_"), "verdict.json")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--superpoint", sp, "--lightglue", lg, "--size", size, "--max-kp", str(max_kp),
+                            "--out", out], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        v = json.load(open(out))
+    except Exception as e:  # noqa: BLE001
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"[:300], "superpoint": sp, "lightglue": lg}
+    cond = {"ok": bool(v.get("ok")) and r.returncode == 0, "superpoint": sp, "lightglue": lg, "skipped": v.get("skipped", {}),
+            "steps": {k: (s if k in ("hip", "pins") else {"ok": s.get("ok")}) for k, s in v.get("steps", {}).items()}}
+    hr = v.get("steps", {}).get("headroom", {})
+    if "max_abs_activation" in hr:
+        cond["steps"]["headroom"]["largest_activation"] = {net: max(a.values()) for net, a in hr["max_abs_activation"].items() if a}
+        cond["steps"]["headroom"]["fp16_max"] = FP16_MAX
+    if "failed" in v:
+        cond["failed"] = v["failed"]
+    return cond
+
+
 def main(argv=None) -> int:
+    if argv is None and "--from-env" in sys.argv[1:]:
+        v = verdict_from_env()
+        print(json.dumps(v if v is not None else {"ok": False, "error": "SUPERSLAM_SP_WEIGHTS / SUPERSLAM_LG_WEIGHTS are not set"}, indent=1))
+        return 0 if v and v["ok"] else 1
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--superpoint", help="superpoint_v1.pth (MagicLeap) or a .safetensors of the same keys")
     ap.add_argument("--lightglue", help="superpoint_lightglue.pth (cvg/LightGlue) or a .safetensors of the same keys")

@@ -1806,6 +1806,7 @@ struct sship_ep {
   float gem_p = 3.f;
   DevBuf d_in, patches, act[4], d_out;
   PinBuf h_out;
+  DevBuf d_ws, d_tail;      // split-K partial sums; the tail's [512] pre-normalisation outputs + its arrival counter
   DevBuf d_img, d_tab;      // u8 entry points: the uploaded image and the resize tables of (tab_h, tab_w) -> (in_h, in_w)
   PinBuf h_img;
   int tab_h = 0, tab_w = 0;
@@ -1882,6 +1883,9 @@ extern "C" int sship_ep_create(const char* weights_path, int input_w, int input_
   for (auto& a : ep->act) SSHIP_HIP_CHECK(a.ensure((size_t)Ho * Wo * 64 * 2));
   SSHIP_HIP_CHECK(ep->d_out.ensure(512 * 4));
   SSHIP_HIP_CHECK(ep->h_out.ensure(512 * 4));
+  SSHIP_HIP_CHECK(ep->d_ws.ensure(ep_splitk_workspace_bytes(input_h, input_w)));
+  SSHIP_HIP_CHECK(ep->d_tail.ensure(1026 * 4));
+  SSHIP_HIP_CHECK(hipMemset(ep->d_tail.p, 0, 1026 * 4));
   SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&ep->stream, hipStreamDefault));
   *out = ep.release();
   return SSHIP_OK;
@@ -1911,15 +1915,16 @@ static int ep_network(sship_ep* ep, float* desc_dev, hipStream_t s) {
     const _Float16* res = a[cur];
     int ho = h, wo = w;
     if (blk.stride == 2) { ho = (h + 1) / 2; wo = (w + 1) / 2; }
-    SSHIP_HIP_CHECK(ep_conv(blk.c1, a[cur], a[f[0]], nullptr, h, w, true, blk.stride == 2, s));
+    float* ws = ep->d_ws.as<float>();
+    SSHIP_HIP_CHECK(ep_conv(blk.c1, a[cur], a[f[0]], nullptr, h, w, true, blk.stride == 2, s, ws));
     if (blk.has_ds) {
       SSHIP_HIP_CHECK(ep_conv(blk.ds, a[cur], a[f[1]], nullptr, h, w, false, blk.stride == 2, s));
       res = a[f[1]];
     }
-    SSHIP_HIP_CHECK(ep_conv(blk.c2, a[f[0]], a[f[2]], res, ho, wo, true, false, s));
+    SSHIP_HIP_CHECK(ep_conv(blk.c2, a[f[0]], a[f[2]], res, ho, wo, true, false, s, ws));
     cur = f[2]; h = ho; w = wo;
   }
-  launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, desc_dev, s);
+  launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, ep->d_tail.as<float>(), ep->d_tail.as<int>() + 1024, desc_dev, s);
   SSHIP_HIP_CHECK(hipGetLastError());
   return SSHIP_OK;
 }

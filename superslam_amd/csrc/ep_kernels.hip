@@ -54,8 +54,74 @@ static hipError_t ep_gemm(const ConvW& w, const _Float16* in, _Float16* out, con
   return launch_igemm<KS, CIN, 64, 8, Epi>(a, w.cout_pad, s);
 }
 
+// ---- split-K for the deep layers ----
+// out[pix][c] = act(sum_z ws[z][pix][c] + bias[c] (+ res[pix][c])): one thread per (pixel, 4 channels); z ascending (one fixed summation order)
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void k_ep_splitk_finish(const float* __restrict__ ws, int ksplit, int npix, int cout, const float* __restrict__ bias,
+                                                          const _Float16* __restrict__ res, _Float16* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int cq = cout >> 2;
+  if (idx >= npix * cq) return;
+  const int pix = idx / cq, c = (idx - pix * cq) * 4;
+  const size_t o = (size_t)pix * cout + c, zs = (size_t)npix * cout;
+  float4 v = *reinterpret_cast<const float4*>(ws + o);
+  for (int z = 1; z < ksplit; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(ws + z * zs + o);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+  v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+  if (RES) {
+    const h4_t r = *reinterpret_cast<const h4_t*>(res + o);
+    v.x += (float)r[0]; v.y += (float)r[1]; v.z += (float)r[2]; v.w += (float)r[3];
+  }
+  if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  *reinterpret_cast<h4_t*>(out + o) = to_h4(v.x, v.y, v.z, v.w);
+}
+// the split this layer gets: every 64-channel chunk its own workgroup layer once the plain launch would leave most CUs idle
+static int ep_ksplit(const ConvW& w, int H, int W, int th) {
+  const int nchunk = w.cin / 64;
+  if (w.ks != 3 || nchunk < 2) return 1;
+  const long wgs = (long)((W + 31) / 32) * ((H + th - 1) / th) * ((w.cout_pad + 63) / 64);
+  int k = 1;
+  while (k * 2 <= nchunk && wgs * k * 2 <= 2L * cu_count()) k *= 2;
+  return k;
+}
+template <int CIN, int TH>
+static hipError_t ep_conv_splitk(const ConvW& w, const _Float16* in, _Float16* out, const _Float16* res, int H, int W, bool relu, bool decim,
+                                 int ksplit, float* ws, hipStream_t s) {
+  IgemmArgs a{};
+  a.in0 = in; a.in1 = in; a.cs0 = CIN; a.cs1 = CIN; a.cin0 = CIN;
+  a.wpack = w.w; a.bias = w.bias; a.B = 1; a.H = H; a.W = W; a.cout = w.cout; a.ostride = w.cout;
+  a.out0 = ws;
+  hipError_t e = decim ? launch_igemm_splitk<3, CIN, 64, TH, EpiPartial<true>>(a, w.cout_pad, ksplit, s)
+                       : launch_igemm_splitk<3, CIN, 64, TH, EpiPartial<false>>(a, w.cout_pad, ksplit, s);
+  if (e != hipSuccess) return e;
+  const int npix = decim ? ((H + 1) / 2) * ((W + 1) / 2) : H * W;
+  const int n = npix * (w.cout / 4);
+  if (res) hipLaunchKernelGGL((k_ep_splitk_finish<true, true>), dim3((n + 255) / 256), dim3(256), 0, s, ws, ksplit, npix, w.cout, w.bias, res, out);
+  else if (relu) hipLaunchKernelGGL((k_ep_splitk_finish<true, false>), dim3((n + 255) / 256), dim3(256), 0, s, ws, ksplit, npix, w.cout, w.bias, res, out);
+  else hipLaunchKernelGGL((k_ep_splitk_finish<false, false>), dim3((n + 255) / 256), dim3(256), 0, s, ws, ksplit, npix, w.cout, w.bias, res, out);
+  return hipGetLastError();
+}
+size_t ep_splitk_workspace_bytes(int in_h, int in_w) {  // upper bound over the layers of a (in_h, in_w) input: ksplit <= cin / 64, maps <= (H / 8) x (W / 8) x 128
+  const size_t h8 = (size_t)(in_h + 7) / 8, w8 = (size_t)(in_w + 7) / 8;
+  return 2 * h8 * w8 * 128 * 4 * 2;   // layer2: 2 x (H/8 x W/8) x 128; layer3: 4 x (H/16 x W/16) x 256 (= half of it); layer4: 8 x (H/32 x W/32) x 512 (a quarter); x 2 headroom
+}
+
 // conv (ks in {1, 3}, cin in {64, 128, 256, 512}; the stem GEMM: ks 1, cin 192) with the epilogue picked at run time
-hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Float16* res, int H, int W, bool relu, bool decim, hipStream_t s) {
+hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Float16* res, int H, int W, bool relu, bool decim, hipStream_t s,
+                   float* ws) {
+  if (ws && w.ks == 3 && w.cin >= 128 && w.cout % 64 == 0) {
+    // small maps: 4-row tiles double the workgroup count; then split the reduction until ~2 workgroups per CU
+    const bool th4 = H * W <= 64 * 64;
+    const int ksplit = ep_ksplit(w, H, W, th4 ? 4 : 8);
+    if (ksplit > 1) {
+      if (w.cin == 128) return th4 ? ep_conv_splitk<128, 4>(w, in, out, res, H, W, relu, decim, ksplit, ws, s) : ep_conv_splitk<128, 8>(w, in, out, res, H, W, relu, decim, ksplit, ws, s);
+      if (w.cin == 256) return th4 ? ep_conv_splitk<256, 4>(w, in, out, res, H, W, relu, decim, ksplit, ws, s) : ep_conv_splitk<256, 8>(w, in, out, res, H, W, relu, decim, ksplit, ws, s);
+      if (w.cin == 512) return th4 ? ep_conv_splitk<512, 4>(w, in, out, res, H, W, relu, decim, ksplit, ws, s) : ep_conv_splitk<512, 8>(w, in, out, res, H, W, relu, decim, ksplit, ws, s);
+    }
+  }
 #define EP_CASE(KS_, CIN_)                                                                                        \
   if (w.ks == KS_ && w.cin == CIN_) {                                                                             \
     if (res) return ep_gemm<KS_, CIN_, EpiEP<true, true, false>>(w, in, out, res, H, W, s);                       \
@@ -63,6 +129,15 @@ hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Flo
                            : ep_gemm<KS_, CIN_, EpiEP<false, false, true>>(w, in, out, nullptr, H, W, s);         \
     return relu ? ep_gemm<KS_, CIN_, EpiEP<true, false, false>>(w, in, out, nullptr, H, W, s)                     \
                 : ep_gemm<KS_, CIN_, EpiEP<false, false, false>>(w, in, out, nullptr, H, W, s);                   \
+  }
+  // layer1 (64 -> 64 at H/4 x W/4, one 64-channel chunk: nothing to split): 4-row tiles double the workgroup count of a small map
+  if (w.ks == 3 && w.cin == 64 && !decim && H * W <= 160 * 160) {
+    IgemmArgs a{};
+    a.in0 = in; a.in1 = in; a.cs0 = 64; a.cs1 = 64; a.cin0 = 64;
+    a.wpack = w.w; a.bias = w.bias; a.B = 1; a.H = H; a.W = W; a.cout = w.cout; a.ostride = w.cout;
+    a.out0 = out; a.out1 = const_cast<_Float16*>(res);
+    if (res) return launch_igemm<3, 64, 64, 4, EpiEP<true, true, false>>(a, w.cout_pad, s);
+    return relu ? launch_igemm<3, 64, 64, 4, EpiEP<true, false, false>>(a, w.cout_pad, s) : launch_igemm<3, 64, 64, 4, EpiEP<false, false, false>>(a, w.cout_pad, s);
   }
   EP_CASE(3, 64) EP_CASE(3, 128) EP_CASE(3, 256) EP_CASE(3, 512)
   EP_CASE(1, 64) EP_CASE(1, 128) EP_CASE(1, 256) EP_CASE(1, 192)
@@ -159,45 +234,103 @@ void launch_ep_maxpool(const _Float16* in, int H, int W, int Ho, int Wo, _Float1
   hipLaunchKernelGGL(k_ep_maxpool, dim3((n + 255) / 256), dim3(256), 0, s, in, H, W, Ho, Wo, out);
 }
 
-// aggregation tail (one workgroup of 512 threads): per-location L2 normalisation over the 512 channels, GeM(p, eps = 1e-6)
-// over the npix locations, Linear(512 -> 512) (weights transposed [in][out] fp32), L2 normalisation -> fp32 [512]
+// aggregation tail: per-location L2 normalisation over the 512 channels, GeM(p, eps = 1e-6) over the npix locations, Linear(512 -> 512)
+// (weights transposed [in][out] fp32), L2 normalisation -> fp32 [512].
+// kTailWg = 8 workgroups of 512 threads.  One workgroup took 42 us - not for bandwidth: thread = channel walked the 256 locations one dependent
+// load + log2 / exp2 at a time.  Now: (1) every workgroup computes the inverse norms of all locations (a wave per location, four locations in
+// flight: one coalesced 1-KB row each, wave_sum); (2) workgroup g pools ITS 64 channels, thread = (channel, 1/8 of the locations), and
+// publishes them; (3) a grid barrier (device counter; the 8 workgroups are co-resident on any device this library accepts) - the Linear needs
+// all 512 pooled values; (4) its 64 outputs, thread = (1/8 of the inputs, output): 128 KB of weights per workgroup; (5) the last workgroup to
+// arrive normalises and resets both counters for the next call (calls of one handle are stream-ordered: include/sship.h).
+constexpr int kTailWg = 8;
 __global__ __launch_bounds__(512) void k_ep_tail(const _Float16* __restrict__ feat, int npix, float p, const float* __restrict__ wt,
-                                                 const float* __restrict__ bias, float* __restrict__ out) {
-  extern __shared__ float s_ep[];  // [npix] inverse norms | [512] pooled | [8] wave partials
+                                                 const float* __restrict__ bias, float* __restrict__ ws, int* __restrict__ counters,
+                                                 float* __restrict__ out) {
+  extern __shared__ float s_ep[];  // [npix] inverse norms | [512] pooled | [512] partials | [8] wave partials
   float* s_inv = s_ep;
   float* s_g = s_ep + npix;
-  float* s_red = s_g + 512;
-  const int t = threadIdx.x;
-  for (int px = t; px < npix; px += 512) {
-    float ss = 0.f;
-    for (int c = 0; c < 512; c += 8) {
-      const h8_t v = *reinterpret_cast<const h8_t*>(feat + (size_t)px * 512 + c);
+  float* s_part = s_g + 512;
+  float* s_red = s_part + 512;
+  __shared__ int s_last;
+  float* g_ws = ws;         // [512] pooled values of all workgroups
+  float* y_ws = ws + 512;   // [512] Linear outputs before the final normalisation
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = blockIdx.x;
+  // (1) inverse norms: F.normalize(dim = channels): x / max(||x||, 1e-12)
+  for (int px0 = wave * 4; px0 < npix; px0 += 32) {
+    h8_t v[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8_t*>(feat + (size_t)min(px0 + u, npix - 1) * 512 + lane * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf((float)v[u][e], (float)v[u][e], ss);
+      ss = wave_sum(ss);
+      if (lane == 0 && px0 + u < npix) s_inv[px0 + u] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
     }
-    s_inv[px] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: x / max(||x||, eps)
   }
   __syncthreads();
-  float acc = 0.f;
-  for (int px = 0; px < npix; ++px) {
-    const float v = fmaxf((float)feat[(size_t)px * 512 + t] * s_inv[px], 1e-6f);
-    acc += exp2f(p * log2f(v));
+  // (2) GeM of channels [64 g, 64 g + 64): (mean over locations of clamp(x, 1e-6)^p)^(1/p); thread (c, q) sums locations q, q + 8, ...
+  {
+    const int c = 64 * g + lane;
+    float acc = 0.f;
+    for (int px = wave; px < npix; px += 8) {
+      const float v = fmaxf((float)feat[(size_t)px * 512 + c] * s_inv[px], 1e-6f);
+      acc += exp2f(p * log2f(v));
+    }
+    s_part[t] = acc;
+    __syncthreads();
+    if (t < 64) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += s_part[q * 64 + t];  // ascending location group: one fixed summation order
+      g_ws[64 * g + t] = exp2f(log2f(sum / (float)npix) / p);
+    }
   }
-  const float mean = acc / (float)npix;
-  s_g[t] = exp2f(log2f(mean) / p);
+  // (3) grid barrier
+  __threadfence();
   __syncthreads();
-  float y = bias[t];
-  for (int c = 0; c < 512; ++c) y = fmaf(wt[(size_t)c * 512 + t], s_g[c], y);
-  float ss = wave_sum(y * y);
-  if ((t & 63) == 0) s_red[t >> 6] = ss;
+  if (t == 0) {
+    atomicAdd(counters + 1, 1);
+    while (__hip_atomic_load(counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  s_g[t] = __hip_atomic_load(g_ws + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // other workgroups' values: device-scope loads, not a stale L1 line
+  __syncthreads();
+  // (4) Linear: outputs [64 g, 64 g + 64); thread (part, output) covers inputs [64 part, 64 part + 64)
+  const int j = 64 * g + lane, part = wave;
+  float d = 0.f;
+#pragma unroll 8
+  for (int c = part * 64; c < part * 64 + 64; ++c) d = fmaf(wt[(size_t)c * 512 + j], s_g[c], d);
+  s_part[t] = d;
+  __syncthreads();
+  if (t < 64) {
+    float y = bias[64 * g + t];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y += s_part[q * 64 + t];
+    y_ws[64 * g + t] = y;
+  }
+  // (5) last workgroup: final L2 normalisation
+  __threadfence();
+  __syncthreads();
+  if (t == 0) s_last = atomicAdd(counters, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const float y = __hip_atomic_load(y_ws + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float ss = wave_sum(y * y);
+  if (lane == 0) s_red[wave] = ss;
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
   for (int w = 0; w < 8; ++w) tot += s_red[w];
   out[t] = y / fmaxf(sqrtf(tot), 1e-12f);
+  if (t == 0) { counters[0] = 0; counters[1] = 0; }
 }
-void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_ep_tail, dim3(1), dim3(512), (size_t)(npix + 512 + 8) * 4, s, feat, npix, p, wt, bias, out);
+// ws: [1024] floats, counters: [2] ints (zero before the first call; the kernel leaves them zero)
+void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* ws, int* counters, float* out,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_ep_tail, dim3(kTailWg), dim3(512), (size_t)(npix + 512 + 512 + 8) * 4, s, feat, npix, p, wt, bias, ws, counters, out);
 }
 
 }  // namespace sship

@@ -45,7 +45,10 @@ struct IgemmArgs {
 
 constexpr int kCP = 72;  // halfs per LDS pixel (64 channels + 8 pad)
 
-template <int KS, int CIN, int CT, int TH, class Epi>
+// SPLITK (EigenPlaces' deep, small-map layers): blockIdx.z owns the 64-channel chunks [z NCHUNK / gridDim.z, (z + 1) NCHUNK / gridDim.z) of
+// the reduction and the epilogue (EpiPartial) writes raw fp32 partial sums; a 16 x 16 x 512 layer is 16 workgroups walking 4.7 MB of
+// weights otherwise.  false: the code is exactly what it was.
+template <int KS, int CIN, int CT, int TH, class Epi, bool SPLITK = false>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   constexpr int HALO = KS / 2, TW = 32, TWH = TW + KS - 1, THH = TH + KS - 1;
   constexpr int MT = CT / 32, NT = TH / 4, NCHUNK = CIN / 64;
@@ -124,16 +127,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     }
   };
 
-  load_in(0);
-  load_w(0);
+  int s_begin = 0, s_end = NSTAGE;
+  if constexpr (SPLITK) {
+    s_begin = (int)blockIdx.z * NCHUNK / (int)gridDim.z * KS;
+    s_end = ((int)blockIdx.z + 1) * NCHUNK / (int)gridDim.z * KS;
+  }
+  load_in(s_begin / KS);
+  load_w(s_begin);
 #pragma unroll 1
-  for (int s = 0; s < NSTAGE; ++s) {
+  for (int s = s_begin; s < s_end; ++s) {
     const int ky = s % KS;
     __syncthreads();  // every wave is done reading the previous stage's tiles
     if (ky == 0) store_in();
     store_w();
     __syncthreads();
-    if (s + 1 < NSTAGE) {
+    if (s + 1 < s_end) {
       if ((s + 1) % KS == 0) load_in((s + 1) / KS);
       load_w(s + 1);
     }
@@ -232,6 +240,31 @@ struct EpiF32 {
   }
 };
 
+// split-K partial sums: raw fp32 accumulators -> ws[z][pixel][cout] (DECIM: only the even (y, x) pixels, at (y / 2, x / 2)); bias, residual
+// and activation are applied by the kernel that adds the gridDim.z partials (ep_kernels.hip: k_ep_splitk_finish)
+template <bool DECIM>
+struct EpiPartial {
+  template <int MT, int NT>
+  static __device__ __forceinline__ void run(const IgemmArgs& p, f16x_t (&acc)[MT][NT], int b, int yb, int x, int cb0, int hh) {
+    const int Ho = DECIM ? (p.H + 1) >> 1 : p.H, Wo = DECIM ? (p.W + 1) >> 1 : p.W;
+    float* out = static_cast<float*>(p.out0) + (size_t)blockIdx.z * Ho * Wo * p.ostride;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = cb0 + m * 32 + hh * 4 + g * 8;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int y = yb + n;
+          if (y >= p.H || x >= p.W || c >= p.cout) continue;
+          if (DECIM && ((y | x) & 1)) continue;
+          *reinterpret_cast<float4*>(out + ((size_t)(DECIM ? y >> 1 : y) * Wo + (DECIM ? x >> 1 : x)) * p.ostride + c) =
+              make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
+        }
+      }
+  }
+};
+
 template <int KS, int CIN, int CT, int TH>
 constexpr size_t igemm_smem_bytes() {
   return (size_t)((TH + KS - 1) * (32 + KS - 1) * kCP + KS * 4 * (CT / 32) * 512) * 2;
@@ -251,6 +284,22 @@ inline hipError_t launch_igemm(const IgemmArgs& a, int cout_pad, hipStream_t str
   }
   const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
   dim3 grid(a.B * tiles_x * tiles_y, (cout_pad + CT - 1) / CT);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+  return hipGetLastError();
+}
+// split-K launch: grid.z = ksplit (a divisor of CIN / 64); B = 1
+template <int KS, int CIN, int CT, int TH, class Epi>
+inline hipError_t launch_igemm_splitk(const IgemmArgs& a, int cout_pad, int ksplit, hipStream_t stream) {
+  constexpr size_t smem = igemm_smem_bytes<KS, CIN, CT, TH>();
+  static bool attr_set = false;
+  auto kern = igemm_kernel<KS, CIN, CT, TH, Epi, true>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
+  dim3 grid(a.B * tiles_x * tiles_y, (cout_pad + CT - 1) / CT, ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
   return hipGetLastError();
 }

@@ -90,12 +90,15 @@ hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int os
                           hipStream_t s);
 
 // ---- ep_kernels.hip : EigenPlaces (ResNet-18 + GeM) ----
+// ws: split-K workspace (ep_splitk_workspace_bytes) or null = never split
 hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Float16* res, int H, int W, bool relu, bool decim,
-                   hipStream_t s);
+                   hipStream_t s, float* ws = nullptr);
+size_t ep_splitk_workspace_bytes(int in_h, int in_w);
 void launch_ep_resize_norm(const uint8_t* src, int stride, int ch, const int* tab, int out_w, int out_h, float* out, hipStream_t s);
 void launch_ep_im2col(const float* x, int H, int W, int Ho, int Wo, _Float16* out, hipStream_t s);
 void launch_ep_maxpool(const _Float16* in, int H, int W, int Ho, int Wo, _Float16* out, hipStream_t s);
-void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* out, hipStream_t s);
+void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* ws, int* counters, float* out,
+                    hipStream_t s);
 
 // ---- lg_kernels.hip ----
 struct LgDims {

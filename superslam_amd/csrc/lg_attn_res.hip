@@ -24,6 +24,12 @@
 #include "kernels.h"
 
 #include <type_traits>
+#include <vector>
+
+// developer aid: -DSSHIP_ATTN_RES_TRACE=1 + SSHIP_ATTN_TRACE=1 prints, per wave index, the mean shader clocks of a workgroup's phases
+#ifndef SSHIP_ATTN_RES_TRACE
+#define SSHIP_ATTN_RES_TRACE 0
+#endif
 
 namespace sship {
 namespace {
@@ -50,7 +56,9 @@ __device__ __forceinline__ void res_wait_vm(int n) {
 __global__ __launch_bounds__(512, 2) void k_lg_attention_res(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                              const _Float16* __restrict__ vt, const int* __restrict__ lens, int NP,
                                                              int cross, _Float16* __restrict__ ctx, int n_wg, int nqsplit, int qper,
-                                                             int ept) {
+                                                             int ept, unsigned long long* __restrict__ trace) {
+  unsigned long long tr[6] = {0, 0, 0, 0, 0, 0};  // 0 entry, 1 first stage landed, 2 end of the staged sweep (pass 0), 3 pass 0 stored, 4 end of the kernel; 5 = barrier wait clocks of the sweep
+  if (SSHIP_ATTN_RES_TRACE && trace) tr[0] = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) char smem_res[];
   _Float16* sK = reinterpret_cast<_Float16*>(smem_res);  // [ept][4 k-steps][64 lanes][8]   (the global fragment image)
   _Float16* sV = sK + (size_t)ept * 2048;                // [ept][2 kk][2 mt][64 lanes][8]
@@ -240,12 +248,16 @@ __global__ __launch_bounds__(512, 2) void k_lg_attention_res(const _Float16* __r
         if (!resident) {
           res_wait_vm(4 * max(mine - 1 - st, 0));  // this wave's DMA instructions that may stay in flight (the Q loads are older than every DMA)
           if (st == 0 && e == 0) pin_q();
+          unsigned long long tb = 0;
+          if (SSHIP_ATTN_RES_TRACE && trace) tb = __builtin_readcyclecounter();
           asm volatile("s_barrier" ::: "memory");  // everybody's share of tiles 4 st .. 4 st + 3 has landed
+          if (SSHIP_ATTN_RES_TRACE && trace) { const unsigned long long tn = __builtin_readcyclecounter(); tr[5] += tn - tb; if (st == 0 && e == 0 && pidx == 0) tr[1] = tn; }
           lo = 4 * st; hi = min(ne, 4 * st + 4);
         }
         run_range(nq_c, e, lo, valid ? hi : lo);
       }
     }
+    if (SSHIP_ATTN_RES_TRACE && trace && pidx == 0) tr[2] = __builtin_readcyclecounter();
     // ---- normalise and store (the register finalisation of k_lg_attention<.., 1, ..>) ----
     if (valid) {
 #pragma unroll
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_attention_res(const _Float16* __r
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores and the next pass's counted loads do not mix
+    if (SSHIP_ATTN_RES_TRACE && trace && pidx == 0) tr[3] = __builtin_readcyclecounter();
   };
   // Pass plan over the workgroup's ntq query tiles: full passes of 16 tiles (two per wave); a remainder r > 8 adds a two-tile pass for
   // the waves w < r - 8 and a single-tile pass for the others; a remainder r <= 8 one single-tile pass for the waves w < r.
@@ -276,6 +289,11 @@ __global__ __launch_bounds__(512, 2) void k_lg_attention_res(const _Float16* __r
   if (rem > 0) {
     const int ta = qlo + 16 * nfull + wave;
     do_pass(std::integral_constant<int, 1>{}, ta, rem > 8 ? wave >= rem - 8 : wave < rem, pidx);
+  }
+  if (SSHIP_ATTN_RES_TRACE && trace && lane == 0) {
+    tr[4] = __builtin_readcyclecounter();
+    unsigned long long* o_ = trace + ((size_t)L * 8 + wave) * 8;
+    o_[0] = tr[1] - tr[0]; o_[1] = tr[2] - tr[1]; o_[2] = tr[3] - tr[2]; o_[3] = tr[4] - tr[3]; o_[4] = tr[5]; o_[5] = tr[4] - tr[0]; o_[6] = 1;
   }
 }
 
@@ -300,8 +318,26 @@ void launch_lg_attention_res(const _Float16* q, const _Float16* k, const _Float1
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kResCapTiles * 8192);
   (void)attr_rc;
   const int n_wg = d.S * 4 * nqsplit;
+  unsigned long long* tbuf = nullptr;
+  static const bool trace_on = SSHIP_ATTN_RES_TRACE && dev_env("SSHIP_ATTN_TRACE") != nullptr;
+  if (trace_on) { (void)hipMalloc(&tbuf, (size_t)n_wg * 64 * 8); (void)hipMemsetAsync(tbuf, 0, (size_t)n_wg * 64 * 8, s); }
   hipLaunchKernelGGL(k_lg_attention_res, dim3((n_wg + 7) / 8 * 8), dim3(512), smem, s, q, k, vt, lens, d.NP, cross ? 1 : 0, ctx, n_wg,
-                     nqsplit, qper, ept);
+                     nqsplit, qper, ept, tbuf);
+  if (trace_on) {
+    std::vector<unsigned long long> h((size_t)n_wg * 64);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    for (int w = 0; w < 8; ++w) {
+      double sum[6] = {0, 0, 0, 0, 0, 0}; long cnt = 0;
+      for (int L = 0; L < n_wg; ++L) {
+        const unsigned long long* r = &h[((size_t)L * 8 + w) * 8];
+        if (r[6]) { for (int i = 0; i < 6; ++i) sum[i] += (double)r[i]; ++cnt; }
+      }
+      if (cnt) fprintf(stderr, "[attn res trace cross=%d wave %d] to first stage=%.0f staged sweep (pass 0)=%.0f store=%.0f later passes=%.0f barrier wait=%.0f total=%.0f clk (%ld workgroups)\n",
+                       (int)cross, w, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, cnt);
+    }
+    (void)hipFree(tbuf);
+  }
 }
 
 }  // namespace sship

@@ -18,7 +18,7 @@ DEV_LIB = os.path.join(ROOT, "superslam_amd", "lib", "variants", "dev.so")
 
 def _env(mode_env):
     """Process environment of one mode: switches select kernels only in the developer build."""
-    env = _env(mode_env)
+    env = dict(os.environ, **mode_env)
     env.pop("SUPERSLAM_HIP_LIBRARY", None)
     if mode_env:
         assert os.path.exists(DEV_LIB), "superslam_amd/lib/variants/dev.so is missing: __graft_entry__.build() produces it"

@@ -47,3 +47,28 @@ def test_kit_refuses_a_checkpoint_with_a_wrong_layer(tmp_path):
     torch.save(to_raw_checkpoint_keys(make_lightglue_weights(1)), str(tmp_path / "lg.pth"))
     rc, v, _ = _run(["--superpoint", str(tmp_path / "sp.pth"), "--lightglue", str(tmp_path / "lg.pth"), "--no-hip"])
     assert rc == 1 and not v["ok"] and "conv3a.weight" in v["steps"]["load"]["error"]
+
+
+def test_env_var_route_feeds_the_kit_and_condenses_the_verdict(tmp_path, monkeypatch):
+    """VERDICT r04 "do this" 8: smoke() and bench.py pick the published checkpoints up from SUPERSLAM_SP_WEIGHTS / SUPERSLAM_LG_WEIGHTS.  Here
+    the seeded weights go through that route in the published layouts (.pth, SuperPoint wrapped in {"model": ...}, raw LightGlue keys)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import real_weights_check as K
+
+    from superslam_amd.weights import make_lightglue_weights, make_superpoint_weights, to_raw_checkpoint_keys
+
+    monkeypatch.delenv("SUPERSLAM_SP_WEIGHTS", raising=False); monkeypatch.delenv("SUPERSLAM_LG_WEIGHTS", raising=False)
+    assert K.verdict_from_env() is None                         # unset: nothing runs, nothing is reported
+    sp_path, lg_path = str(tmp_path / "superpoint_v1.pth"), str(tmp_path / "superpoint_lightglue.pth")
+    torch.save({"model": make_superpoint_weights(0)}, sp_path)
+    torch.save(to_raw_checkpoint_keys(make_lightglue_weights(1)), lg_path)
+    monkeypatch.setenv("SUPERSLAM_SP_WEIGHTS", sp_path)
+    assert K.verdict_from_env()["ok"] is False                  # one of the two: refused with a message
+    monkeypatch.setenv("SUPERSLAM_LG_WEIGHTS", lg_path)
+    v = K.verdict_from_env(size="120x160", max_kp=64)
+    assert v["ok"] and v["steps"]["load"]["ok"] and v["steps"]["pins"]["ok"] and v["steps"]["headroom"]["ok"], v
+    assert v["steps"]["headroom"]["largest_activation"]["superpoint"] < v["steps"]["headroom"]["fp16_max"]
+    if not torch.cuda.is_available():
+        assert "no GPU" in v["skipped"]["hip"]
+    monkeypatch.setenv("SUPERSLAM_LG_WEIGHTS", str(tmp_path / "missing.pth"))
+    assert K.verdict_from_env(size="120x160", max_kp=64)["ok"] is False
