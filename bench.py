@@ -747,7 +747,13 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
                           "includes": "u8 H2D (0.5 MB, pinned) + device resize to 512x512 / normalise + ResNet-18 + GeM + FC + D2H, synchronous (sship_ep_infer_u8)",
                           "ms_per_descriptor_device_resident": round(ep_dev.value, 4), "gflop": 19.0, "input": [H, W],
                           "achieved_tflops_device_resident": round(19.0 / ep_dev.value, 1),
-                          "frac_of_mfma_peak_device_resident": round(19.0 / ep_dev.value / MFMA_PEAK_TFLOPS, 4)}
+                          "frac_of_mfma_peak_device_resident": round(19.0 / ep_dev.value / MFMA_PEAK_TFLOPS, 4),
+                          "bound": "launch latency: ~45 dependent launches of 3-18 us on ONE 512x512 image (per-kernel table: profiles/r05_ep_kernel_stats.txt)"}
+    out["roofline_mfma"].append({"kernel": "eigenplaces (ResNet-18 + GeM + FC, one 512x512 image, whole descriptor)", "launch_ms": round(ep_dev.value, 4),
+                                 "gflop_per_launch": 19.0, "achieved": round(19.0 / ep_dev.value, 1), "unit": "TFLOP/s",
+                                 "frac": round(19.0 / ep_dev.value / MFMA_PEAK_TFLOPS, 4),
+                                 "timing": "sship_ep_bench: 20 back-to-back device-resident descriptors on the handle's stream (not one launch: ~45 kernels)",
+                                 "bound": "launch latency at batch 1 (off the per-frame path: once per keyframe on the loop-closure thread)"})
     ep.close()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spw, lgw, pairs[0][0], pairs[0][1], K)

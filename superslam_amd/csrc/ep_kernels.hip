@@ -274,9 +274,17 @@ __global__ __launch_bounds__(512) void k_ep_tail(const _Float16* __restrict__ fe
   {
     const int c = 64 * g + lane;
     float acc = 0.f;
-    for (int px = wave; px < npix; px += 8) {
-      const float v = fmaxf((float)feat[(size_t)px * 512 + c] * s_inv[px], 1e-6f);
-      acc += exp2f(p * log2f(v));
+    for (int px0 = wave; px0 < npix; px0 += 64) {  // eight locations in flight per thread (one dependent 2-byte load at a time was most of the kernel)
+      _Float16 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = feat[(size_t)min(px0 + 8 * u, npix - 1) * 512 + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int px = px0 + 8 * u;
+        const float x = fmaxf((float)v[u] * s_inv[min(px, npix - 1)], 1e-6f);
+        const float e = __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));  // x in [1e-6, 1]: no denormal handling needed (v_log_f32 / v_exp_f32)
+        acc += px < npix ? e : 0.f;
+      }
     }
     s_part[t] = acc;
     __syncthreads();

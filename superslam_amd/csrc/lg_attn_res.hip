@@ -35,6 +35,10 @@ namespace sship {
 namespace {
 
 constexpr int kResCapTiles = 19;  // key tiles resident at a time: 19 x (4 KB K + 4 KB V^T) = 152 KB
+#ifndef SSHIP_RES_AHEAD
+#define SSHIP_RES_AHEAD 1
+#endif
+constexpr int kResAhead = SSHIP_RES_AHEAD;  // DMA rounds (of four tiles) in flight ahead of the stage being computed; 1..4 (A/B: -DSSHIP_RES_AHEAD=n; 5 = everything at once)
 
 __device__ __forceinline__ float res_max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float res_max_xor32(float x) {
@@ -82,27 +86,26 @@ __global__ __launch_bounds__(512, 2) void k_lg_attention_res(const _Float16* __r
   const unsigned lds_k = (unsigned)(uintptr_t)sK, lds_v = (unsigned)(uintptr_t)sV;
   const int nep = (ntk + ept - 1) / ept;           // key epochs actually needed by this sequence's key count
 
-  // ---- DMA of epoch e (ne tiles) : group g = 2 * tile + (0: K, 1: V^T), 4 KB each; wave w moves groups w, w + 8, ... so that round r
-  // (groups 8 r .. 8 r + 7) completes tiles 4 r .. 4 r + 3.  Returns the number of rounds in which THIS wave issued a group.
-  auto fill = [&](int e, int ne) __attribute__((always_inline)) -> int {
-    const int ng = 2 * ne;
-    int mine = 0;
-    for (int g = wave; g < ng; g += 8, ++mine) {
-      const int tl = g >> 1, isv = g & 1;
-      const unsigned long long ga = (unsigned long long)(uintptr_t)((isv ? VT : K) + (size_t)(e * ept + tl) * 2048);
-      const unsigned long long gs = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ga) |
-                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ga >> 32)) << 32);
-      const unsigned dst = __builtin_amdgcn_readfirstlane((isv ? lds_v : lds_k) + (unsigned)tl * 4096u);
-      unsigned keep;
-      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %1, %3\n\t"
-                   "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-                   "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
-                   "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
-                   "s_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(gs) : "memory");
-    }
-    return mine;
+  // ---- DMA of epoch e (ne tiles): group g = 2 * tile + (0: K, 1: V^T), 4 KB each; in round r wave w moves group 8 r + w, so that round r
+  // completes tiles 4 r .. 4 r + 3.  Rounds are issued kResAhead ahead of the stage that reads them, NOT all at once: with every CU of the
+  // launch asking for its whole 152 KB at the same moment the memory system delivered the FIRST four tiles of a workgroup after 16 k clocks -
+  // about when it delivered the last ones (profiles/r05_b_*: 39 MB in flight at ~5 TB/s) - and nothing was computed meanwhile.
+  auto fill_round = [&](int e, int ne, int r) __attribute__((always_inline)) {
+    const int g = 8 * r + wave;
+    if (g >= 2 * ne) return;
+    const int tl = g >> 1, isv = g & 1;
+    const unsigned long long ga = (unsigned long long)(uintptr_t)((isv ? VT : K) + (size_t)(e * ept + tl) * 2048);
+    const unsigned long long gs = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ga) |
+                                  ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ga >> 32)) << 32);
+    const unsigned dst = __builtin_amdgcn_readfirstlane((isv ? lds_v : lds_k) + (unsigned)tl * 4096u);
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(gs) : "memory");
   };
 
   // ---- per-pass state: up to two query tiles of this wave ----
@@ -237,21 +240,25 @@ __global__ __launch_bounds__(512, 2) void k_lg_attention_res(const _Float16* __r
     if (resident || nep == 0) { res_wait_vm(0); pin_q(); }
     for (int e = 0; e < nep; ++e) {
       const int ne = min(ept, ntk - e * ept);
-      int mine = 0, nst = 1;
+      int nst = 1;
       if (!resident) {
         if (pidx > 0 || e > 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the old content
-        mine = fill(e, ne);
         nst = (2 * ne + 7) >> 3;  // DMA rounds = stages of four tiles
+        for (int r = 0; r < min(nst, kResAhead); ++r) fill_round(e, ne, r);
       }
       for (int st = 0; st < nst; ++st) {
         int lo = 0, hi = ne;
         if (!resident) {
-          res_wait_vm(4 * max(mine - 1 - st, 0));  // this wave's DMA instructions that may stay in flight (the Q loads are older than every DMA)
+          // this wave's DMA groups of the rounds behind st that are already issued may stay in flight (the Q loads are older than every DMA)
+          int later = 0;
+          for (int r = st + 1; r < min(nst, st + kResAhead); ++r) later += (8 * r + wave < 2 * ne) ? 1 : 0;
+          res_wait_vm(4 * later);
           if (st == 0 && e == 0) pin_q();
           unsigned long long tb = 0;
           if (SSHIP_ATTN_RES_TRACE && trace) tb = __builtin_readcyclecounter();
           asm volatile("s_barrier" ::: "memory");  // everybody's share of tiles 4 st .. 4 st + 3 has landed
           if (SSHIP_ATTN_RES_TRACE && trace) { const unsigned long long tn = __builtin_readcyclecounter(); tr[5] += tn - tb; if (st == 0 && e == 0 && pidx == 0) tr[1] = tn; }
+          if (st + kResAhead < nst) fill_round(e, ne, st + kResAhead);  // the round this stage's compute hides
           lo = 4 * st; hi = min(ne, 4 * st + 4);
         }
         run_range(nq_c, e, lo, valid ? hi : lo);

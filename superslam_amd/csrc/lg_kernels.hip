@@ -163,6 +163,9 @@ __device__ __forceinline__ float max_xor32(float x) {
 #ifndef SSHIP_ATTN_TRACE_BUILD
 #define SSHIP_ATTN_TRACE_BUILD 0
 #endif
+#ifndef SSHIP_ATTN_LDS_STORE
+#define SSHIP_ATTN_LDS_STORE 1  // KS == 1: context rows leave as whole 128-byte lines through a wave-private LDS patch (0: per-lane 8-byte stores, A/B builds)
+#endif
 #ifndef SSHIP_ATTN_REGFIN
 #define SSHIP_ATTN_REGFIN 1  // KS == 1: normalise and store the context straight from the accumulators (0: through the merge buffer, A/B builds)
 #endif
@@ -177,7 +180,7 @@ __device__ __forceinline__ float max_xor32(float x) {
 //   3  = 2 with the QK^T MFMA chains of both query tiles issued first and interleaved (see `tile`).
 //      (another variant with the row sums on the matrix pipe as well - l += ones(32 x 16) P, two more MFMAs per key tile instead of
 //      eight v_dot2_f32_f16 - measured no faster than 2 and sat on the mscores0 bar: profiles/r03_a_attention_variants.txt; removed).
-// Energy ablations of the attention kernel (build.py --variant ... -DSSHIP_ATTN_ABL=n, scripts/dev/run_energy_abl_attn.sh): 1 no MFMAs (operands still
+// Energy ablations of the attention kernel (build.py --variant ... -DSSHIP_ATTN_ABL=n, scripts/dev/energy_abl.sh attn): 1 no MFMAs (operands still
 // delivered), 2 P = the exponent's argument instead of exp2 of it (no v_exp_f32 in the key loop).  Results are wrong by design.
 #ifndef SSHIP_ATTN_ABL
 #define SSHIP_ATTN_ABL 0
@@ -394,11 +397,18 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     // merge path below with one partial: 0 + o * 1 * inv), without the 68 LDS writes, the barrier that made a workgroup's waves
     // wait for its slowest one, and the 66 LDS reads per lane.
     if (!active) return;
+    // The context rows leave as WHOLE 128-byte lines: a lane owns one query and 4 consecutive channels per register quad, so storing from
+    // the accumulators is 16 eight-byte stores per query tile that each touch 32 different rows (512 sixteen-byte pieces of lines; the store
+    // phase was 5.6 k of a wave's ~53 k clocks, profiles/r05_a_*).  Instead the tile goes through a wave-private 32 x 144-byte LDS patch
+    // (the kernel uses no other LDS on this path; 36-dword row stride: the 64 lanes' ds_write_b64 hit 64 distinct bank pairs) and comes back
+    // as 16 bytes per lane, 8 lanes per row: 4 stores of eight full lines.  Same values, same bytes.
+    _Float16* patch = reinterpret_cast<_Float16*>(smem_attn) + wave * (32 * 72);
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       if (q0 + t * 32 >= nq) break;
       const float lt = l[t] + __shfl_xor(l[t], 32, 64);
       const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+#if !SSHIP_ATTN_LDS_STORE  // A/B builds: the per-lane 8-byte stores straight from the accumulators
       _Float16* orow = ctx + ((size_t)s * NP + q0 + t * 32 + j) * 256 + h * 64;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -406,6 +416,22 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<h4_t*>(orow + mt * 32 + 8 * g + 4 * hh) =
               to_h4(o[t][mt][4 * g] * inv, o[t][mt][4 * g + 1] * inv, o[t][mt][4 * g + 2] * inv, o[t][mt][4 * g + 3] * inv);
+      continue;
+#endif
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<h4_t*>(patch + j * 72 + mt * 32 + 8 * g + 4 * hh) =
+              to_h4(o[t][mt][4 * g] * inv, o[t][mt][4 * g + 1] * inv, o[t][mt][4 * g + 2] * inv, o[t][mt][4 * g + 3] * inv);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its LDS operations execute in order; this orders the compiler
+      _Float16* obase = ctx + ((size_t)s * NP + q0 + t * 32) * 256 + h * 64 + (lane & 7) * 8;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        *reinterpret_cast<h8_t*>(obase + (size_t)row * 256) = *reinterpret_cast<const h8_t*>(patch + row * 72 + (lane & 7) * 8);
+      }
+      asm volatile("" ::: "memory");  // the next tile's writes stay behind these reads
     }
     if (SSHIP_ATTN_TRACE_BUILD && trace && lane == 0) {
       unsigned long long* o_ = trace + ((size_t)L * 4 + wave) * 4;
@@ -464,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
 template <int QT, int KS, int V>
 static void launch_attn_v(const _Float16* q, const _Float16* k, const _Float16* vt, const int* lens, LgDims d, bool cross,
                         _Float16* ctx, hipStream_t s) {
-  constexpr size_t smem = KS == 1 && SSHIP_ATTN_REGFIN ? 0 : (size_t)QT * 4 * 34 * 64 * sizeof(float);
+  constexpr size_t smem = KS == 1 && SSHIP_ATTN_REGFIN ? (size_t)4 * 32 * 72 * sizeof(_Float16) : (size_t)QT * 4 * 34 * 64 * sizeof(float);  // register finalisation: the four waves' 32 x 144-byte store patches
   constexpr int QPB = 32 * QT * (4 / KS);  // queries per workgroup
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lg_attention<QT, KS, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   (void)attr_rc;  // thread-safe one-time opt-in (magic static)
@@ -1087,7 +1113,7 @@ static hipError_t launch_ffn(int nt, int tokens, int extra_wg, hipStream_t s, A.
 #ifndef SSHIP_FFN4_BSTORE
 #define SSHIP_FFN4_BSTORE 5
 #endif
-// Energy ablations of the throughput kernel (build.py --variant ... -DSSHIP_FFN4_ABL=n, scripts/dev/run_energy_abl.sh: rocm-smi power x launch
+// Energy ablations of the throughput kernel (build.py --variant ... -DSSHIP_FFN4_ABL=n, scripts/dev/energy_abl.sh ffn: rocm-smi power x launch
 // time per variant): 1 no MFMAs (operands still delivered), 2 no LayerNorm / GELU math, 4 every weight fragment read from offset 0 (the
 // loads of a phase collapse into one: no L2 -> register stream), 8 no projection epilogue (rotary, conversion, stores).  Results are wrong by design.
 #ifndef SSHIP_FFN4_ABL
