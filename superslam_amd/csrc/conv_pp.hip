@@ -2,7 +2,7 @@
 //
 // The strip kernel (conv_strip.hip) runs ONE workgroup per CU (72 KiB of weights + the input tile fill the LDS) and
 // its 8 waves move through  stage -> MFMA -> epilogue  in lock-step, so the matrix pipe idles while they all do
-// VALU / LDS / VMEM work (ablation in DESIGN.md: epilogue 19-30 %, conv1a phase 12 %, MFMA loop itself ~85 % efficient).
+// VALU / LDS / VMEM work (ablation in profiles/NOTES_r01_r04_design_history.md: epilogue 19-30 %, conv1a phase 12 %, MFMA loop itself ~85 % efficient).
 // CDNA4 puts two waves of a 512-thread workgroup on every SIMD; here they get complementary roles:
 //
 //   group g = wave >> 2 (waves g*4 .. g*4+3: one per SIMD) owns its own 8 x 32 pixel tile stream and its own LDS input

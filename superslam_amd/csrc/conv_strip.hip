@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512) void conv3x3_strip(StripArgs p) {
       }
     }
     // ---- epilogue: bias + ReLU (+ 2x2 max-pool), fp16 channels-last ----
-    // The ablation showed the old epilogue (8-byte stores, ds_bpermute shuffles, bias re-loads per tile)
+    // The ablation (profiles/NOTES_r01_r04_design_history.md) showed the old epilogue (8-byte stores, ds_bpermute shuffles, bias re-loads per tile)
     // cost 24-51 % of the kernel.  Now: bias lives in registers, the pool's x-exchange is a DPP quad_perm, and
     // v_permlane32_swap pairs the two half-waves' 4-channel quads into 8 consecutive channels per lane, so every
     // store is 16 B (half as many store instructions, 32-B sectors fully written).

@@ -4,7 +4,7 @@
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        16 element-wise positions, each a [64 cout x 64 cin] GEMM over the 2x2 output tiles:
 //   16 MFMA-MACs per 2x2 outputs and channel pair instead of 36 - 2.25x fewer matrix instructions, paid for with VALU transforms.
 //
-// What shapes the kernel on gfx950:
+// What shapes the kernel on gfx950 (profiles/NOTES_r01_r04_design_history.md item 33):
 //   * the 16 transformed weight sets are 128 KB and must be LDS-resident (streamed they would cost 1 KB of L2 traffic per output pixel):
 //     32 KB are left for input, so the input tile (10 x 34 halo pixels for 8 x 32 outputs) goes through a ring of three
 //     16-CHANNEL chunks (10.9 KB each, LDS-DMA, one MFMA k-step per chunk) instead of being resident whole;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino64(WinoArgs p) {
   // ---- LDS-DMA of one 16-channel chunk: 11 instructions of 64 lanes x 16 B; wave w issues instructions 3 w, 3 w + 1, 3 w + 2 with ONE M0 and
   // instruction offsets 0 / 1024 / 2048 (the offset moves the global AND the LDS address: the per-lane source offsets are biased by
   // 2048 - 1024 k and the buffer base by -2048).  The first version wrote M0 per instruction: 1.5 k clocks of issue per chunk - rewriting M0
-  // between LDS-DMAs serialises them ----
+  // between LDS-DMAs serialises them (profiles/NOTES_r01_r04_design_history.md item 16) ----
   // position P = 64 i + lane (16-byte units) holds halo pixel (r, c), half u with  q = P >> 1, r = q / 34, rem = q % 34,
   // c = 2 (rem % 17) + rem / 17, u = (P & 1) ^ ((r >> 1) & 1)
   unsigned voff[3];

@@ -3,7 +3,7 @@
 //   x += ffn.3( GELU( LayerNorm( ffn.0( cat[x, ctx] ) ) ) ),  then the projection that consumes the new x (CrossBlock [to_qk|to_v],
 //   the next layer's Wqkv with rotary, or final_proj + matchability), out_proj / to_out folded into ffn.0 on the host.
 //
-// Why another kernel (VERDICT r03 "do this" 1; measurements in DESIGN.md items 13, 20 and the round-4 entry):
+// Why another kernel (VERDICT r03 "do this" 1; measurements in profiles/NOTES_r01_r04_design_history.md items 13, 20 and the round-4 entry):
 //   * k_lg_ffn4 streams the block's 1.0-1.15 MB of packed weights from L2 ONCE PER 64 TOKENS per workgroup.  The three GEMMs of a
 //     64-token tile are 2 048-2 304 MFMAs = 16-18 k clocks of one CU's matrix pipes, and 1.15 MB at the 64 B/clk a CU's vector
 //     L1 delivers are 18 k clocks as well: at 64 tokens per weight pass the weight stream alone caps the kernel at the matrix

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void k_lg_ffn(const _Float16* __restrict__ 
   const int tile0 = blockIdx.x;
   const int nwg = tail.n_main > 0 ? tail.n_main : (int)gridDim.x;  // workgroups that walk the tiles
   if (tail.n_main > 0 && tile0 >= nwg) {
-    // Prefetch role (latency mode).  One pair's launch covers 38 of 256 CUs and every layer has its own
+    // Prefetch role (latency mode; profiles/NOTES_r01_r04_design_history.md round 4).  One pair's launch covers 38 of 256 CUs and every layer has its own
     // 1.0-1.15 MB of weights (21 MB over the 18 blocks: no XCD's 4 MB L2 keeps them from one frame to the next), so each FFN launch used
     // to stream its weights at HBM / MALL latency: 19-23 us for a launch whose arithmetic is 3 us.  The surplus workgroups of THIS
     // launch read the NEXT launch's weights once per XCD - workgroup ids are dealt round-robin over the 8 XCDs, so prefetch
