@@ -170,10 +170,12 @@ def self_check(torch, np, fe, chunk, stream, wdir, max_kp):
         res["mutual_flips"] += int((flagdiff & (ds > PATH_VS_PATH_BAR)).sum())
         res["small_flips"] = res.get("small_flips", 0) + int((flagdiff & (ds <= PATH_VS_PATH_BAR)).sum())
         res["mscores_maxd"] = max(res["mscores_maxd"], float(ds[same].max()) if same.any() else 0.0)
+        res["mscores_maxd_all"] = max(res.get("mscores_maxd_all", 0.0), float(ds.max()) if k0 else 0.0)   # incl. rows whose mutual flag flips (keep regressions visible)
         res["min_pair_agreement"] = min(res["min_pair_agreement"], float((ma == mb).mean()) if k0 else 1.0)
         res["matches_per_pair_path"] += int((mb >= 0).sum())
     sp1.close(); lg1.close()
     res["mscores_maxd"] = round(res["mscores_maxd"], 5)
+    res["mscores_maxd_all"] = round(res.get("mscores_maxd_all", 0.0), 5)
     res["min_pair_agreement"] = round(res["min_pair_agreement"], 4)
     res["agreement"] = round(res["matches_equal_rows"] / max(1, res["matches_rows"]), 5)
     res["ok"] = bool(res["kp_bit_identical"] == P and res["desc_max_ulp"] <= 1 and res["agreement"] >= 0.99
