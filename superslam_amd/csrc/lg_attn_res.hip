@@ -1,5 +1,11 @@
 // LightGlue attention for throughput batches with the keys RESIDENT in LDS (gfx950, wave64).
 //
+// STATUS: developer build only (build.py DEV_SOURCES; SUPERSLAM_HIP_ATTN=res).  Built for VERDICT r04 "do this" 1, bit-identical to the shipped
+// kernel, MEASURED 4-12 % SLOWER (profiles/r05_a_attention_lds_resident_keys_rejected.txt): with every operand in LDS the key loop runs at the
+// same ~575 clocks per 32 x 32 score tile as with operands streamed from L2 (it is VALU-issue bound), and the resident form adds a fill that
+// cannot overlap the previous workgroup (9.5-16.6 k clocks), a second single-tile pass (19 query tiles on 8 waves) and loses CU sharing with the
+// other half-batch's FFN.  The premise in the next paragraphs is the hypothesis the kernel was built to test, kept as written.
+//
 // What it computes is k_lg_attention<2, 1, 3> (lg_kernels.hip) instruction for instruction: flash-style attention over
 // head_dim 64, S^T = K Q^T "swapped" so a lane owns one query column, the reference exponent riding in the QK^T MFMA
 // chain, P in fp16, key tiles visited in ascending order by ONE wave per query tile - so the context rows are bit-identical
