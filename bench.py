@@ -627,6 +627,19 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
                     "keypoints_found": [int(n2.min()), int(n2.max())], "pairs_timed": reps * CH * P, "timed_seconds": round(dt2, 3),
                     "algorithmic_gflop_per_pair": round(fp2 / 1e9, 2), "effective_tflops": round(reps * CH * P / dt2 * fp2 / 1e12, 2),
                     "matches_last_call": int((fe2.matches0 >= 0).sum().item())}
+    # the matcher's stages at 1 024 keypoints (the quadratic attention term is 2.9x the 600-keypoint one): isolated re-launches over lg2's last call
+    n2k, rows1024 = K2, []
+    fl2 = {"lg_self_attention": 2.0 * S * 4 * n2k * n2k * 64 * 2, "lg_cross_attention": 2.0 * S * 4 * n2k * n2k * 64 * 2,
+           "lg_self_ffn+to_qk|to_v": 2.0 * S * n2k * (512 * 512 + 512 * 256 + 256 * 256 + 512 * 256),
+           "lg_cross_ffn+wqkv": 2.0 * S * n2k * (512 * 512 + 512 * 256 + 256 * 256 + 768 * 256)}
+    for sid, name in ((1, "lg_self_attention"), (2, "lg_cross_attention"), (3, "lg_self_ffn+to_qk|to_v"), (4, "lg_cross_ffn+wqkv")):
+        msv = C.c_float(0)
+        _lib.check(L.sship_lg_bench_stage(lg2._h, sid, 10, C.byref(msv)))
+        tf = fl2[name] / (msv.value * 1e-3) / 1e12
+        rows1024.append({"kernel": name + " @ n = 1024", "launch_ms": round(msv.value, 4), "gflop_per_launch": round(fl2[name] / 1e9, 2),
+                         "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                         "timing": "isolated re-launch over the state of the last 1 024-keypoint call"})
+    out["roofline_mfma"].extend(rows1024)
     sp2.close(); lg2.close()
 
     lat_probe("after_n1024")
