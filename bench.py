@@ -14,7 +14,9 @@ collective (weak scaling: every rank runs its own batch); `value` = all pairs of
 Prints ONE JSON line with the driver's fields plus
   self_check    : after the timed region, one chunk's batched outputs against the per-pair path (keypoints bit-identical,
                   descriptors <= 1 ulp, matches within the matcher bars); the process exits non-zero if it fails
-  roofline      : the dominant kernel (conv1a+conv1b+pool, 36 % of the pair's FLOPs); `frac` from the IN-SITU launch duration
+  roofline      : the dominant kernel (conv1a+conv1b+pool, 36 % of the pair's FLOPs); `traffic` = HBM bytes per launch measured IN THIS RUN
+                  (two rocprofv3 --pmc passes as child processes; `traffic_source` says measured or, after a failure, read from the committed file);
+                  `frac` from the IN-SITU launch duration
                   (HIP events around the launch inside profiled headline calls on the stream it runs on - the figure
                   rocprofv3 --kernel-trace of the same steps reproduces), `frac_isolated` from 20 back-to-back re-launches
   roofline_mfma : the same for every matrix-core stage (conv layers in-situ + isolated, LightGlue stages isolated)
@@ -262,6 +264,11 @@ def main():
     ap.add_argument("--max-kp", type=int, default=600, help="superpoint.max_keypoints (600 = the KITTI YAML)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="warm-up + timed steps only (profiling passes)")
+    ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=True,
+                    help="(default) measure roofline.traffic IN THIS RUN: two rocprofv3 --pmc passes over `bench.py --headline-only` as child processes "
+                         "(scripts/pmc_traffic.sh, ~20-60 s, 150 s limit; needs rocprofv3 on PATH).  On any failure the figure is READ from "
+                         "profiles/pmc_conv1ab.json instead and traffic_source says so")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: re-execute as N ranks under torch.distributed.run (does not return then)
@@ -484,6 +491,33 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
                                   + (" (kernel source unchanged)" if pj.get("conv_pp_sha16") == cur else " (KERNEL SOURCE CHANGED since the collection)"))
         except Exception:
             traffic, traffic_source = None, None
+    import shutil
+
+    if getattr(args, "measure_traffic", False) and world == 1 and shutil.which("rocprofv3"):
+        # the PMC passes run NOW, as child processes on the same GPU, and the figure below is this run's
+        import subprocess
+
+        mj = os.path.join(wdir, "pmc_traffic_now.json")
+        try:
+            import signal
+
+            pr = subprocess.Popen(["bash", os.path.join(ROOT, "scripts", "pmc_traffic.sh"), str(P), mj], cwd=ROOT, stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL, start_new_session=True)   # its own process group: a timeout takes rocprofv3 and its python along
+            try:
+                pr.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                raise
+            if pr.returncode != 0:
+                raise RuntimeError(f"scripts/pmc_traffic.sh exited with {pr.returncode}")
+            kj = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_conv1ab.json")))
+            if kj.get("pairs_per_call") == P and kj.get("headline_launches_only"):
+                traffic = kj.get("hbm_bytes_per_launch")
+                traffic_source = ("MEASURED IN THIS RUN: scripts/pmc_traffic.sh as a child process (two separate rocprofv3 --pmc passes over `bench.py --headline-only`, "
+                                  "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch per MI355X_MICROARCH.md), collected " + str(kj.get("collected_at")))
+        except Exception as e:  # noqa: BLE001 - fall back to the file figure already in `traffic`
+            traffic_source = (traffic_source or "") + f" [--measure-traffic failed: {type(e).__name__}: {e}]"[:200]
     alg_bytes = B * (H * W + (H // 2) * (W // 2) * 64 * 2)   # u8 image in, pooled fp16 64-ch map out
     probe = {}
     for name, rnd in (("zero_operands", 0), ("random_operands", 1)):

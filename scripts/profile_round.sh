@@ -8,7 +8,7 @@ if [ -z "$SKIPT" ]; then
   timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
   cp gpurun_out/parity_report.json $O/ 2>/dev/null
 fi
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"   # roofline.traffic measured in this very run (child rocprofv3 passes)
 cd /tmp && export TMPDIR=/tmp
 # kernel stats of the SAME command's headline part only: every launch in this trace belongs to a timed-region-shaped step
 rm -rf /tmp/prof_ks; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python $R/bench.py --headline-only --steps 3 --warmup 1 --pairs $P > $O/bench_under_rocprof.json 2> /tmp/prof_ks.err
