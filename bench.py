@@ -493,7 +493,8 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
             traffic, traffic_source = None, None
     import shutil
 
-    if getattr(args, "measure_traffic", False) and world == 1 and shutil.which("rocprofv3"):
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")  # never nest profilers
+    if getattr(args, "measure_traffic", False) and world == 1 and shutil.which("rocprofv3") and not under_profiler:
         # the PMC passes run NOW, as child processes on the same GPU, and the figure below is this run's
         import subprocess
 
