@@ -196,8 +196,17 @@ def scale_extras(torch, dist, rank, world, backend, dt_own, pairs_per_rank):
                              events on the launch stream; GB/s = bytes a rank RECEIVES from its world - 1 peers / time, and the gathered
                              tensor is checked against every rank's own pattern;
       rccl_world           : the rank count RCCL itself reports for the communicator.
-    Never fails the bench line: an error becomes a string in the record."""
+    Never fails the bench line: an error becomes a string in the record.  Every phase that contains a collective of the C-ABI communicator is
+    preceded by a VOTE over torch.distributed (which the timed region has just used): if any rank failed the phase before, all ranks skip the
+    rest together - a rank that raised must not leave the others waiting inside a collective."""
     res = {"backend": backend}
+    dev = "cuda" if backend == "nccl" else "cpu"
+
+    def all_ok(ok):
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item()) == 0
+
     try:
         own = [None] * world
         dist.all_gather_object(own, round(pairs_per_rank / dt_own, 2))
@@ -205,16 +214,49 @@ def scale_extras(torch, dist, rank, world, backend, dt_own, pairs_per_rank):
         if backend != "nccl":
             res["exchange"] = "skipped: RCCL only (this run's collectives go through " + backend + ")"
             return res
+        import ctypes as C
+
         from superslam_amd import _lib
         from superslam_amd.shard import RcclComm
 
-        comm = RcclComm(rank, world)
-        res["rccl_world"] = int(_lib.lib().sship_comm_world(comm._h))
+        L = _lib.lib()
+        # phase 1: the communicator id on rank 0 (no collective), then a broadcast that every rank takes part in whatever happened
+        box, err = [None], None
+        if rank == 0:
+            try:
+                buf = C.create_string_buffer(128)
+                _lib.check(L.sship_comm_unique_id(buf))
+                box[0] = buf.raw
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"[:300]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            res["error"] = "rank 0 could not create an RCCL id" + (": " + err if err else "")
+            return res
+        # phase 2: communicator (a collective inside RCCL: every rank calls it; the vote afterwards catches a rank whose call returned an error)
+        comm, err = None, None
+        try:
+            comm = RcclComm(rank, world, id_bytes=box[0])
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+        if not all_ok(comm is not None):
+            res["error"] = "sship_comm_create failed on at least one rank" + (": " + err if err else "")
+            return res
+        res["rccl_world"] = int(L.sship_comm_world(comm._h))
         ex = {}
         for name, units, kp in (("configs[2] offline extraction", 512, 600), ("configs[4] camera rig tick", 1, 1024)):
-            desc = torch.full((units, kp, 256), float(rank + 1), dtype=torch.float16, device="cuda")
-            kpt = torch.full((units, kp, 3), float(rank) + 0.5, dtype=torch.float32, device="cuda")
-            n = torch.full((units,), kp - rank, dtype=torch.int32, device="cuda")
+            bufs, err = None, None
+            try:   # allocation only: no collective in here
+                desc = torch.full((units, kp, 256), float(rank + 1), dtype=torch.float16, device="cuda")
+                kpt = torch.full((units, kp, 3), float(rank) + 0.5, dtype=torch.float32, device="cuda")
+                n = torch.full((units,), kp - rank, dtype=torch.int32, device="cuda")
+                bufs = (desc, kpt, n)
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"[:300]
+            if not all_ok(bufs is not None):
+                ex[name] = "skipped: a rank could not allocate its buffers" + (": " + err if err else "")
+                continue
+            desc, kpt, n = bufs
             for _ in range(2):
                 da, ka, na = comm.gather_features(desc, kpt, n)
             torch.cuda.synchronize()
@@ -229,10 +271,11 @@ def scale_extras(torch, dist, rank, world, backend, dt_own, pairs_per_rank):
             per_rank = units * kp * (512 + 12) + units * 4
             t = torch.tensor([ms], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ex[name] = {"bytes_per_rank": per_rank, "ms": round(float(t.item()), 4), "gathered_equals_ranks_patterns": ok,
+            okall = all_ok(ok)
+            ex[name] = {"bytes_per_rank": per_rank, "ms": round(float(t.item()), 4), "gathered_equals_ranks_patterns_on_every_rank": okall,
                         "ingest_gb_per_s_per_rank": round(per_rank * (world - 1) / (float(t.item()) * 1e-3) / 1e9, 2),
                         "aggregate_gb_per_s": round(per_rank * (world - 1) * world / (float(t.item()) * 1e-3) / 1e9, 2)}
-            del desc, kpt, n, da, ka, na
+            del desc, kpt, n, da, ka, na, bufs
         res["exchange"] = ex
         comm.close()
     except Exception as e:  # noqa: BLE001 - the curve must survive a failing extra
