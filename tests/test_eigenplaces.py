@@ -204,6 +204,40 @@ def test_device_preprocessing_equals_the_host_form_bit_for_bit(ep_weights):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("in_w,in_h", [(512, 384), (320, 320), (224, 160)])
+def test_other_engine_sizes_against_the_oracle(ep_weights, in_w, in_h):
+    """The engine size is a constructor argument (EigenPlaces(engine, input_width, input_height), include/EigenPlaces.h:24-26): other sizes change
+    which layers split their reduction, the tile counts (partial tiles, maps narrower than a 32-pixel tile) and the number of locations the GeM
+    tail pools (12 x 16, 10 x 10, 5 x 7).  Descriptor against the fp64 oracle at the bars of the 512 x 512 test; asynchronous device entry point on
+    the caller's stream against the synchronous one, bit for bit."""
+    import ctypes as C
+
+    from superslam_amd import _lib
+
+    sd, path = ep_weights
+    _lib.init(0)
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.sship_ep_create(path.encode(), in_w, in_h, C.byref(h)))
+    img = make_frame(376, 1241, 11)
+    d = np.zeros(512, np.float32)
+    _lib.check(L.sship_ep_infer_u8(h, img.ctypes.data, 376, 1241, 1241, 1, d.ctypes.data))
+    ref = E.compute_global_descriptor(sd, img, in_w, in_h, dtype=torch.float64)
+    dmax, cos = float(np.abs(d - ref).max()), float(d @ ref)
+    print(f"EigenPlaces {in_w} x {in_h}: max|d| {dmax:.2e}, cosine {cos:.7f}")
+    assert np.isfinite(d).all() and dmax <= 2e-3 and cos >= 0.9999
+    st = torch.cuda.Stream()
+    dimg = torch.from_numpy(img).cuda()
+    dout = torch.zeros(512, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):   # back-to-back calls on a side stream: the tail's counters must come back to zero every time
+        _lib.check(L.sship_ep_infer_u8_device(h, dimg.data_ptr(), 376, 1241, 1241, 1, dout.data_ptr(), st.cuda_stream))
+    st.synchronize()
+    np.testing.assert_array_equal(dout.cpu().numpy(), d)
+    L.sship_ep_destroy(h)
+
+
+@pytest.mark.gpu
 def test_global_descriptor_vs_oracle(ep_weights, parity_report):
     from superslam_amd import EigenPlaces
 
