@@ -1110,6 +1110,9 @@ static hipError_t launch_ffn(int nt, int tokens, int extra_wg, hipStream_t s, A.
 // epilogue stores as buffer stores: 1 = x, 2 = V^T, 4 = q / k.  The V^T variant (2) produces wrong matches on the GPU although its
 // ISA reads correctly (bisected with this switch; not understood - suspect the same soffset handling in hipcc 7.2 that the empty
 // asm in wstore works around), so V^T keeps its flat stores: 4 of the 27 stores of a tile.
+#ifndef SSHIP_FFN4_XROWS
+#define SSHIP_FFN4_XROWS 1  // the residual stream's new rows are stored from the LDS tile as whole 512-byte rows (0: 32-byte pieces straight from the accumulators; A/B: LightGlue call -2 %, bit-identical, profiles/r05_c_*)
+#endif
 #ifndef SSHIP_FFN4_BSTORE
 #define SSHIP_FFN4_BSTORE 5
 #endif
@@ -1382,8 +1385,10 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
         const auto s1 = __builtin_amdgcn_permlane32_swap(hi[2 * gp], hi[2 * gp + 1], false, false);
         const uint4 unit = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         const int c = wave * 64 + m * 32 + (2 * gp + hh) * 8;
-        if (SSHIP_FFN4_BSTORE & 1) wstore(rx, xrow16, (long long)(t0 + n * 32) * 256 + wave * 64 + m * 32 + 2 * gp * 8, wq_t{s0[0], s1[0], s0[1], s1[1]});
-        else *reinterpret_cast<uint4*>(x + (t0 + n * 32 + j) * 256 + c) = unit;
+        if constexpr (!(SSHIP_FFN4_XROWS && NEXT_MT > 0)) {
+          if (SSHIP_FFN4_BSTORE & 1) wstore(rx, xrow16, (long long)(t0 + n * 32) * 256 + wave * 64 + m * 32 + 2 * gp * 8, wq_t{s0[0], s1[0], s0[1], s1[1]});
+          else *reinterpret_cast<uint4*>(x + (t0 + n * 32 + j) * 256 + c) = unit;
+        }
         if constexpr (NEXT_MT > 0) *reinterpret_cast<uint4*>(s_x + (n * 32 + j) * kFfnLd + c) = unit;
       }
     }
@@ -1392,6 +1397,17 @@ __global__ __launch_bounds__(256, 2) void k_lg_ffn4(const _Float16* __restrict__
   if constexpr (NEXT_MT > 0) {
     __syncthreads();
     stamp(7);
+    if constexpr (SSHIP_FFN4_XROWS && !PROJ) {
+      // The new x leaves from the LDS tile as WHOLE 512-byte rows (a wave's stores above would be 32-byte pieces of 32 different rows each: a token's row
+      // is assembled by the four waves): wave w copies rows [16 w, 16 w + 16), two rows per instruction, 16 bytes per lane.  The stores are in
+      // flight under the projection's MFMAs.
+#pragma unroll
+      for (int r2 = 0; r2 < NTOK / 8; ++r2) {
+        const int row = wave * (NTOK / 4) + 2 * r2 + hh;
+        const uint4 u = *reinterpret_cast<const uint4*>(s_x + row * kFfnLd + j * 8);
+        *reinterpret_cast<uint4*>(x + (t0 + row) * 256 + j * 8) = u;
+      }
+    }
     // ---- fused next projection: two passes; pass p = row block cb = wave + 4 p of the tile-interleaved packing
     // (block cb holds M-tile m = rows (8 m + cb) * 32 .. + 31: one tile of each 256-row segment), K = 256 ----
     const int NP = pj.np, nt32 = NP >> 5;
