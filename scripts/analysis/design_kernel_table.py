@@ -22,7 +22,7 @@ ROWS = [  # (bench key, table name, work per pair, one-line design)
     ("lg_wqkv0_proj", "`k_lg_ffn4<3,true,PROJ>` first Wqkv (`lg_kernels.hip`)", "0.47 GFLOP", "the FFN kernel's projection stage on its own (rotary epilogue, Q/K/V^T written in fragment order)"),
     ("lg_self_attention", "`k_lg_attention<2,1,3>` ×9 self (`lg_kernels.hip`)", "9 × 0.74 GFLOP", "swapped QKᵀ (lane owns a query), reference exponent riding in the QKᵀ MFMA chain, interleaved chains of two query tiles, K/V^T fragments prefetched a tile ahead, XCD-aware workgroup mapping, register finalisation; round 5: context rows leave as whole 128-B lines through a wave-private LDS patch"),
     ("lg_cross_attention", "… ×9 cross", "9 × 0.74 GFLOP", "same launch shape; sequence s attends to s^1"),
-    ("lg_self_ffn+to_qk|to_v", "`k_lg_ffn4<2,…>` ×9 SelfBlock FFN + CrossBlock projection", "9 × 1.42 GFLOP", "4 waves per workgroup, 2 workgroups per CU, 64-token tile: ffn.0 (out_proj folded) → LayerNorm → GELU (degree-4 minimax σ form) → ffn.3 + residual → next projection on the tile already in LDS; weights stream from L2 through a register ring"),
+    ("lg_self_ffn+to_qk|to_v", "`k_lg_ffn4<2,…>` ×9 SelfBlock FFN + CrossBlock projection", "9 × 1.42 GFLOP", "4 waves per workgroup, 2 workgroups per CU, 64-token tile: ffn.0 (out_proj folded) → LayerNorm → GELU (degree-4 minimax σ form) → ffn.3 + residual → next projection on the tile already in LDS; weights stream from L2 through a register ring; round 5: the new x rows leave from the LDS tile as whole 512-B rows"),
     ("lg_cross_ffn+wqkv", "`k_lg_ffn4<3,…>` ×8 CrossBlock FFN + next Wqkv", "8 × 1.51 GFLOP", "same"),
     ("lg_last_ffn+final_proj", "`k_lg_ffn4<1,…>` last FFN + final_proj + matchability", "1.32 GFLOP", "same"),
     ("lg_assign_pass1_lse", "`k_assign_stream<0>` log-sum-exp pass", "0.18 GFLOP (executed ×2: both orientations)", "sim tiles recomputed on the matrix cores in both orientations so every statistic is lane-local; the fp32 [N,N] matrix never exists"),
