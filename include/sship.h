@@ -284,7 +284,11 @@ int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_out);
  * the descriptor equals sship_ep_infer(sship_ep_preprocess(img)) bit for bit.
  *   sship_ep_infer_u8         host image, host descriptor; synchronous (returns after the handle's stream has drained);
  *   sship_ep_infer_u8_device  device image, device descriptor [512] f32, asynchronous on `stream` (NULL = legacy default stream).  One
- *                             call in flight per handle (the activations live in the handle). */
+ *                             call in flight per handle (the activations live in the handle: calls of one handle must be ordered, on one
+ *                             stream or by events).  The FIRST call with a new source size (h, w) allocates and uploads that size's resize
+ *                             tables (hipMalloc + a blocking copy; not legal under stream capture - warm each size up first); the tables
+ *                             are immutable afterwards, so later calls are purely asynchronous.  The descriptor's bits do not depend on
+ *                             the device's CU count or partition mode (the split-K factors are functions of the layer shapes only). */
 int sship_ep_infer_u8(sship_ep* ep, const uint8_t* img, int h, int w, int stride, int channels, float* desc_out);
 int sship_ep_infer_u8_device(sship_ep* ep, const uint8_t* img_dev, int h, int w, int stride, int channels, float* desc_out_dev, void* stream);
 /* Measurement hook: `iters` back-to-back sship_ep_infer_u8_device calls on the handle's stream over a resident image; average ms. */

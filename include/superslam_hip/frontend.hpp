@@ -1,7 +1,7 @@
 // superslam_hip/frontend.hpp - header-only C++17 host layer above the C ABI (include/sship.h).
 //
 // Mirrors the reference's inference classes with OpenCV-free value types so that it builds anywhere:
-//   superslam_hip::FreeList / DescriptorPool / DeviceDescriptors   <- include/DescriptorPool.h:13-91
+//   superslam_hip::DescriptorPool / DeviceDescriptors   <- include/DescriptorPool.h:13-24,46-91 (the FreeList of :25-44 is sship_pool_*)
 //   superslam_hip::Features, MatchResult, IFeatureExtractor, IFeatureMatcher <- include/InferenceInterfaces.h:12-59
 //   superslam_hip::SuperPoint   <- include/SuperPoint.h:36-54   (ctor, initialize, infer, extract, extract_stereo)
 //   superslam_hip::LightGlue    <- include/LightGlue.h:33-63    (ctors, initialize, shared_engine, match x3,
@@ -47,25 +47,8 @@ struct DeviceDescriptors {
   bool empty() const { return data == nullptr || count == 0; }
 };
 
-// Host-only slot bookkeeping, identical semantics to the reference's FreeList (LIFO, -1 when exhausted).
-class FreeList {
-public:
-  explicit FreeList(int n) : n_(n) {
-    for (int i = n - 1; i >= 0; --i) free_slots_.push_back(i);
-  }
-  int acquire() {
-    if (free_slots_.empty()) return -1;
-    const int slot = free_slots_.back();
-    free_slots_.pop_back();
-    return slot;
-  }
-  void release(int slot) { free_slots_.push_back(slot); }
-  int in_use() const { return n_ - static_cast<int>(free_slots_.size()); }
-
-private:
-  int n_;
-  std::vector<int> free_slots_;
-};
+// Slot bookkeeping (the reference's FreeList, DescriptorPool.h:25-44: LIFO, -1 when exhausted) lives behind the C ABI:
+// sship_pool_acquire / sship_pool_release / sship_pool_in_use.  There is no host-side copy of it here.
 
 // Pool handle shared by every DeviceDescriptors copy.  It holds its own REFERENCE on the C-side bookkeeping
 // (sship_pool_retain), so a handle may outlive the extractor object - whose sship_sp_destroy frees the device slots and

@@ -2,7 +2,9 @@
 
 PARITY: TRUNK PINNED AGAINST transformers' ResNet-18 (oracle/pin_hf.py: bit-identical feature maps in fp64 with the same
 weights, tests/test_oracle_pins_hf.py); AGGREGATION HEAD PINNED BY FORMULA ONLY (tests/test_eigenplaces.py: a second numpy fp64 derivation + torch's
-lp_pool2d agree to 1e-12, seven mutations break it) - the hub package itself is absent; PREPROCESSING (OpenCV cv::resize) UNPINNED.  The network comes from ``torch.hub.load("gmberton/eigenplaces", "get_trained_model", backbone="ResNet18",
+lp_pool2d agree to 1e-12, seven mutations break it) - the hub package itself is absent; PREPROCESSING (OpenCV cv::resize): coordinates, clamping
+and weights pinned against torch's independent bilinear interpolation to < 1 gray level (tests/test_eigenplaces.py), the fixed-point rounding
+sequence rests on OpenCV's published source (OpenCV absent).  The network comes from ``torch.hub.load("gmberton/eigenplaces", "get_trained_model", backbone="ResNet18",
 fc_output_dim=512)`` (/root/reference/utils/convert_eigenplaces_to_onnx.py:54-60), i.e. third-party code + torchvision's
 ResNet-18, neither present in /root/reference nor in this image, and the pre/post-processing uses OpenCV (absent).  This file
 restates the published definitions:

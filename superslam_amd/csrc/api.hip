@@ -1807,9 +1807,13 @@ struct sship_ep {
   DevBuf d_in, patches, act[4], d_out;
   PinBuf h_out;
   DevBuf d_ws, d_tail;      // split-K partial sums; the tail's [512] pre-normalisation outputs + its arrival counter
-  DevBuf d_img, d_tab;      // u8 entry points: the uploaded image and the resize tables of (tab_h, tab_w) -> (in_h, in_w)
+  DevBuf d_img;             // u8 entry points: the uploaded image
   PinBuf h_img;
-  int tab_h = 0, tab_w = 0;
+  // resize tables of (src_h, src_w) -> (in_h, in_w), one IMMUTABLE device buffer per source size seen (a dataset has one; a rig a few).
+  // A set is written once, before its first use, and never touched again: no call on any stream can observe a table changing under it, so
+  // the asynchronous entry point needs no device-wide synchronisation (round 5 re-used one buffer behind a hipDeviceSynchronize).
+  struct Tables { int h = 0, w = 0; DevBuf d; };
+  std::vector<std::unique_ptr<Tables>> tables;
 };
 extern "C" void sship_ep_destroy(sship_ep* ep) {
   bind_thread();
@@ -1916,12 +1920,13 @@ static int ep_network(sship_ep* ep, float* desc_dev, hipStream_t s) {
     int ho = h, wo = w;
     if (blk.stride == 2) { ho = (h + 1) / 2; wo = (w + 1) / 2; }
     float* ws = ep->d_ws.as<float>();
-    SSHIP_HIP_CHECK(ep_conv(blk.c1, a[cur], a[f[0]], nullptr, h, w, true, blk.stride == 2, s, ws));
+    const size_t wsb = ep->d_ws.bytes;
+    SSHIP_HIP_CHECK(ep_conv(blk.c1, a[cur], a[f[0]], nullptr, h, w, true, blk.stride == 2, s, ws, wsb));
     if (blk.has_ds) {
       SSHIP_HIP_CHECK(ep_conv(blk.ds, a[cur], a[f[1]], nullptr, h, w, false, blk.stride == 2, s));
       res = a[f[1]];
     }
-    SSHIP_HIP_CHECK(ep_conv(blk.c2, a[f[0]], a[f[2]], res, ho, wo, true, false, s, ws));
+    SSHIP_HIP_CHECK(ep_conv(blk.c2, a[f[0]], a[f[2]], res, ho, wo, true, false, s, ws, wsb));
     cur = f[2]; h = ho; w = wo;
   }
   launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, ep->d_tail.as<float>(), ep->d_tail.as<int>() + 1024, desc_dev, s);
@@ -1939,18 +1944,27 @@ extern "C" int sship_ep_infer(sship_ep* ep, const float* chw_host, float* desc_o
   memcpy(desc_out, ep->h_out.p, 512 * 4);
   return SSHIP_OK;
 }
-// resize tables of (h, w) -> (in_h, in_w): rebuilt only when the source size changes (a dataset has one)
-static int ep_tables(sship_ep* ep, int h, int w) {
-  if (ep->tab_h == h && ep->tab_w == w) return SSHIP_OK;
+// resize tables of (h, w) -> (in_h, in_w).  The first call with a new source size allocates and uploads its set (hipMalloc + a blocking copy of
+// ~ 8 (in_w + in_h) ints: not legal under stream capture - run one call per source size before capturing); every later call only looks it up.
+constexpr size_t kEpMaxTableSets = 16;
+static int ep_tables(sship_ep* ep, int h, int w, const int** tab_out) {
+  for (const auto& t : ep->tables)
+    if (t->h == h && t->w == w) { *tab_out = t->d.as<int>(); return SSHIP_OK; }
   std::vector<int> t[8];
   superslam_hip::resize_bilinear_coeffs(ep->in_w, w, t[0], t[1], t[2], t[3]);
   superslam_hip::resize_bilinear_coeffs(ep->in_h, h, t[4], t[5], t[6], t[7]);
   std::vector<int> flat;
   for (auto& v : t) flat.insert(flat.end(), v.begin(), v.end());
-  SSHIP_HIP_CHECK(ep->d_tab.ensure(flat.size() * 4));
-  SSHIP_HIP_CHECK(hipDeviceSynchronize());  // a call still reading the old tables (another stream) finishes first; rare path
-  SSHIP_HIP_CHECK(hipMemcpy(ep->d_tab.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
-  ep->tab_h = h; ep->tab_w = w;
+  if (ep->tables.size() >= kEpMaxTableSets) {  // a stream of ever-changing sizes: drop the oldest set once nothing can still be reading it
+    SSHIP_HIP_CHECK(hipDeviceSynchronize());
+    ep->tables.erase(ep->tables.begin());
+  }
+  auto set = std::make_unique<sship_ep::Tables>();
+  SSHIP_HIP_CHECK(set->d.ensure(flat.size() * 4));
+  SSHIP_HIP_CHECK(hipMemcpy(set->d.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));  // a fresh buffer nobody reads yet
+  set->h = h; set->w = w;
+  *tab_out = set->d.as<int>();
+  ep->tables.push_back(std::move(set));
   return SSHIP_OK;
 }
 static int ep_check_image(const void* img, int h, int w, int stride, int channels, const char* who) {
@@ -1963,9 +1977,10 @@ extern "C" int sship_ep_infer_u8_device(sship_ep* ep, const uint8_t* img_dev, in
   bind_thread();
   if (!ep || !desc_out_dev) return fail(SSHIP_ERR_INVALID, "ep_infer_u8_device: null argument");
   if (int rc = ep_check_image(img_dev, h, w, stride, channels, "ep_infer_u8_device")) return rc;
-  if (int rc = ep_tables(ep, h, w)) return rc;
+  const int* tab = nullptr;
+  if (int rc = ep_tables(ep, h, w, &tab)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  launch_ep_resize_norm(img_dev, stride, channels, ep->d_tab.as<int>(), ep->in_w, ep->in_h, ep->d_in.as<float>(), s);
+  launch_ep_resize_norm(img_dev, stride, channels, tab, ep->in_w, ep->in_h, ep->d_in.as<float>(), s);
   return ep_network(ep, desc_out_dev, s);
 }
 extern "C" int sship_ep_infer_u8(sship_ep* ep, const uint8_t* img, int h, int w, int stride, int channels, float* desc_out) {
@@ -1987,21 +2002,20 @@ extern "C" int sship_ep_infer_u8(sship_ep* ep, const uint8_t* img, int h, int w,
 extern "C" int sship_ep_bench(sship_ep* ep, const uint8_t* img_dev, int h, int w, int stride, int channels, int iters, float* avg_ms) {
   bind_thread();
   if (!ep || !avg_ms || iters <= 0) return fail(SSHIP_ERR_INVALID, "ep_bench: bad arguments");
+  if (int rc = ep_check_image(img_dev, h, w, stride, channels, "ep_bench")) return rc;
   hipStream_t s = ep->stream;
-  if (int rc = sship_ep_infer_u8_device(ep, img_dev, h, w, stride, channels, ep->d_out.as<float>(), s)) return rc;  // warm
-  hipEvent_t e0, e1;
-  SSHIP_HIP_CHECK(hipEventCreate(&e0));
-  SSHIP_HIP_CHECK(hipEventCreate(&e1));
-  SSHIP_HIP_CHECK(hipEventRecord(e0, s));
+  if (int rc = sship_ep_infer_u8_device(ep, img_dev, h, w, stride, channels, ep->d_out.as<float>(), s)) return rc;  // warm (also uploads the tables)
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto drop = [&](int rc) { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); return rc; };
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return drop(fail(SSHIP_ERR_HIP, "ep_bench: hipEventCreate failed"));
+  if (hipEventRecord(e0, s) != hipSuccess) return drop(fail(SSHIP_ERR_HIP, "ep_bench: hipEventRecord failed"));
   for (int i = 0; i < iters; ++i)
-    if (int rc = sship_ep_infer_u8_device(ep, img_dev, h, w, stride, channels, ep->d_out.as<float>(), s)) return rc;
-  SSHIP_HIP_CHECK(hipEventRecord(e1, s));
-  SSHIP_HIP_CHECK(hipEventSynchronize(e1));
+    if (int rc = sship_ep_infer_u8_device(ep, img_dev, h, w, stride, channels, ep->d_out.as<float>(), s)) return drop(rc);
   float ms = 0.f;
-  SSHIP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+    return drop(fail(SSHIP_ERR_HIP, "ep_bench: timing failed"));
   *avg_ms = ms / iters;
-  return SSHIP_OK;
+  return drop(SSHIP_OK);
 }
 
 // ====================================================================================================

@@ -78,13 +78,16 @@ __global__ __launch_bounds__(256) void k_ep_splitk_finish(const float* __restric
   if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
   *reinterpret_cast<h4_t*>(out + o) = to_h4(v.x, v.y, v.z, v.w);
 }
-// the split this layer gets: every 64-channel chunk its own workgroup layer once the plain launch would leave most CUs idle
+// the split this layer gets: every 64-channel chunk its own workgroup layer once the plain launch would leave most CUs idle.
+// The target is a CONSTANT (two workgroups per CU of the full 256-CU part), not the CU count of the device the process happens to see: the
+// split fixes the fp32 summation order of the deep layers, and a descriptor's bits must not depend on the partition mode or a CU mask.
+constexpr long kEpSplitTargetWgs = 512;
 static int ep_ksplit(const ConvW& w, int H, int W, int th) {
   const int nchunk = w.cin / 64;
   if (w.ks != 3 || nchunk < 2) return 1;
   const long wgs = (long)((W + 31) / 32) * ((H + th - 1) / th) * ((w.cout_pad + 63) / 64);
   int k = 1;
-  while (k * 2 <= nchunk && wgs * k * 2 <= 2L * cu_count()) k *= 2;
+  while (k * 2 <= nchunk && wgs * k * 2 <= kEpSplitTargetWgs) k *= 2;
   return k;
 }
 template <int CIN, int TH>
@@ -104,18 +107,35 @@ static hipError_t ep_conv_splitk(const ConvW& w, const _Float16* in, _Float16* o
   else hipLaunchKernelGGL((k_ep_splitk_finish<false, false>), dim3((n + 255) / 256), dim3(256), 0, s, ws, ksplit, npix, w.cout, w.bias, res, out);
   return hipGetLastError();
 }
-size_t ep_splitk_workspace_bytes(int in_h, int in_w) {  // upper bound over the layers of a (in_h, in_w) input: ksplit <= cin / 64, maps <= (H / 8) x (W / 8) x 128
-  const size_t h8 = (size_t)(in_h + 7) / 8, w8 = (size_t)(in_w + 7) / 8;
-  return 2 * h8 * w8 * 128 * 4 * 2;   // layer2: 2 x (H/8 x W/8) x 128; layer3: 4 x (H/16 x W/16) x 256 (= half of it); layer4: 8 x (H/32 x W/32) x 512 (a quarter); x 2 headroom
+// Exact bound over the layers of a (in_h, in_w) engine: the map sizes follow the real ceil chain (stem stride 2, max-pool stride 2, then one
+// stride-2 block per level), and a split layer needs cin / 64 x output pixels x cout floats at most.  (Round 5 sized this as "layer2 + 2x
+// headroom"; per-level ceil rounding ate the headroom on engines below ~64 x 64 - ADVICE r05: a 40 x 40 engine wrote 64 KB into 51 KB.)
+size_t ep_splitk_workspace_bytes(int in_h, int in_w) {
+  int h = (in_h - 1) / 2 + 1, w = (in_w - 1) / 2 + 1;  // stem
+  h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;            // MaxPool2d(3, 2, 1): layer1 (one 64-channel chunk, never split)
+  size_t need = 0;
+  const int planes[3] = {128, 256, 512};
+  int cin = 64;
+  for (int L = 0; L < 3; ++L) {
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;      // block 0 conv1 decimates; every other conv of the level runs at (ho, wo)
+    const size_t npix = (size_t)ho * wo;
+    const size_t kmax = (size_t)planes[L] / 64;         // conv2 / block 1: cin = planes; block 0 conv1: cin = the previous level's planes (smaller)
+    need = need > kmax * npix * planes[L] ? need : kmax * npix * planes[L];
+    (void)cin; cin = planes[L]; h = ho; w = wo;
+  }
+  return need * sizeof(float);
 }
 
 // conv (ks in {1, 3}, cin in {64, 128, 256, 512}; the stem GEMM: ks 1, cin 192) with the epilogue picked at run time
 hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Float16* res, int H, int W, bool relu, bool decim, hipStream_t s,
-                   float* ws) {
+                   float* ws, size_t ws_bytes) {
   if (ws && w.ks == 3 && w.cin >= 128 && w.cout % 64 == 0) {
     // small maps: 4-row tiles double the workgroup count; then split the reduction until ~2 workgroups per CU
     const bool th4 = H * W <= 64 * 64;
-    const int ksplit = ep_ksplit(w, H, W, th4 ? 4 : 8);
+    int ksplit = ep_ksplit(w, H, W, th4 ? 4 : 8);
+    // never write past the workspace the caller really holds (ep_splitk_workspace_bytes is exact for the ResNet-18 chain; this guards any other caller)
+    const size_t npix_out = decim ? (size_t)((H + 1) / 2) * ((W + 1) / 2) : (size_t)H * W;
+    while (ksplit > 1 && (size_t)ksplit * npix_out * w.cout * sizeof(float) > ws_bytes) ksplit >>= 1;
     if (ksplit > 1) {
       if (w.cin == 128) return th4 ? ep_conv_splitk<128, 4>(w, in, out, res, H, W, relu, decim, ksplit, ws, s) : ep_conv_splitk<128, 8>(w, in, out, res, H, W, relu, decim, ksplit, ws, s);
       if (w.cin == 256) return th4 ? ep_conv_splitk<256, 4>(w, in, out, res, H, W, relu, decim, ksplit, ws, s) : ep_conv_splitk<256, 8>(w, in, out, res, H, W, relu, decim, ksplit, ws, s);
@@ -236,25 +256,24 @@ void launch_ep_maxpool(const _Float16* in, int H, int W, int Ho, int Wo, _Float1
 
 // aggregation tail: per-location L2 normalisation over the 512 channels, GeM(p, eps = 1e-6) over the npix locations, Linear(512 -> 512)
 // (weights transposed [in][out] fp32), L2 normalisation -> fp32 [512].
-// kTailWg = 8 workgroups of 512 threads.  One workgroup took 42 us - not for bandwidth: thread = channel walked the 256 locations one dependent
-// load + log2 / exp2 at a time.  Now: (1) every workgroup computes the inverse norms of all locations (a wave per location, four locations in
-// flight: one coalesced 1-KB row each, wave_sum); (2) workgroup g pools ITS 64 channels, thread = (channel, 1/8 of the locations), and
-// publishes them; (3) a grid barrier (device counter; the 8 workgroups are co-resident on any device this library accepts) - the Linear needs
-// all 512 pooled values; (4) its 64 outputs, thread = (1/8 of the inputs, output): 128 KB of weights per workgroup; (5) the last workgroup to
-// arrive normalises and resets both counters for the next call (calls of one handle are stream-ordered: include/sship.h).
+// kTailWg = 8 workgroups of 512 threads, TWO launches (round 6).  Round 5 ran both halves in one kernel around a hand-rolled spin barrier in a
+// plain launch: co-residency of the 8 workgroups was assumed, not requested - on the loop-closure thread the kernel shares the GPU with the
+// tracker's persistent conv kernels, exactly where 8 workgroups need not start together, and an aborted call left the barrier counter poisoned
+// (ADVICE r05).  The Linear needs all 512 pooled values, so the kernel boundary IS the barrier: ~1.5 us of launch gap instead
+// of a spin that can last a whole foreign kernel.
+//   k_ep_tail_pool: (1) every workgroup computes the inverse norms of all locations (a wave per location, four locations in flight: one
+//     coalesced 1-KB row each, wave_sum); (2) workgroup g pools ITS 64 channels, thread = (channel, 1/8 of the locations), and publishes them.
+//     It also zeroes the arrival counter of the second kernel, so a previous call that died mid-way cannot poison this one.
+//   k_ep_tail_fc: (3) workgroup g computes its 64 outputs, thread = (1/8 of the inputs, output): 128 KB of weights per workgroup; (4) the last
+//     workgroup to ARRIVE (an atomic ticket - nobody waits) normalises.
 constexpr int kTailWg = 8;
-__global__ __launch_bounds__(512) void k_ep_tail(const _Float16* __restrict__ feat, int npix, float p, const float* __restrict__ wt,
-                                                 const float* __restrict__ bias, float* __restrict__ ws, int* __restrict__ counters,
-                                                 float* __restrict__ out) {
-  extern __shared__ float s_ep[];  // [npix] inverse norms | [512] pooled | [512] partials | [8] wave partials
+__global__ __launch_bounds__(512) void k_ep_tail_pool(const _Float16* __restrict__ feat, int npix, float p, float* __restrict__ g_ws,
+                                                      int* __restrict__ counters) {
+  extern __shared__ float s_ep[];  // [npix] inverse norms | [512] partials
   float* s_inv = s_ep;
-  float* s_g = s_ep + npix;
-  float* s_part = s_g + 512;
-  float* s_red = s_part + 512;
-  __shared__ int s_last;
-  float* g_ws = ws;         // [512] pooled values of all workgroups
-  float* y_ws = ws + 512;   // [512] Linear outputs before the final normalisation
+  float* s_part = s_ep + npix;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = blockIdx.x;
+  if (g == 0 && t == 0) counters[0] = 0;  // k_ep_tail_fc's ticket (stream-ordered after this kernel)
   // (1) inverse norms: F.normalize(dim = channels): x / max(||x||, 1e-12)
   for (int px0 = wave * 4; px0 < npix; px0 += 32) {
     h8_t v[4];
@@ -271,41 +290,37 @@ __global__ __launch_bounds__(512) void k_ep_tail(const _Float16* __restrict__ fe
   }
   __syncthreads();
   // (2) GeM of channels [64 g, 64 g + 64): (mean over locations of clamp(x, 1e-6)^p)^(1/p); thread (c, q) sums locations q, q + 8, ...
-  {
-    const int c = 64 * g + lane;
-    float acc = 0.f;
-    for (int px0 = wave; px0 < npix; px0 += 64) {  // eight locations in flight per thread (one dependent 2-byte load at a time was most of the kernel)
-      _Float16 v[8];
+  const int c = 64 * g + lane;
+  float acc = 0.f;
+  for (int px0 = wave; px0 < npix; px0 += 64) {  // eight locations in flight per thread (one dependent 2-byte load at a time was most of the kernel)
+    _Float16 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = feat[(size_t)min(px0 + 8 * u, npix - 1) * 512 + c];
+    for (int u = 0; u < 8; ++u) v[u] = feat[(size_t)min(px0 + 8 * u, npix - 1) * 512 + c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int px = px0 + 8 * u;
-        const float x = fmaxf((float)v[u] * s_inv[min(px, npix - 1)], 1e-6f);
-        const float e = __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));  // x in [1e-6, 1]: no denormal handling needed (v_log_f32 / v_exp_f32)
-        acc += px < npix ? e : 0.f;
-      }
-    }
-    s_part[t] = acc;
-    __syncthreads();
-    if (t < 64) {
-      float sum = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sum += s_part[q * 64 + t];  // ascending location group: one fixed summation order
-      g_ws[64 * g + t] = exp2f(log2f(sum / (float)npix) / p);
+    for (int u = 0; u < 8; ++u) {
+      const int px = px0 + 8 * u;
+      const float x = fmaxf((float)v[u] * s_inv[min(px, npix - 1)], 1e-6f);
+      const float e = __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));  // x in [1e-6, 1]: no denormal handling needed (v_log_f32 / v_exp_f32)
+      acc += px < npix ? e : 0.f;
     }
   }
-  // (3) grid barrier
-  __threadfence();
+  s_part[t] = acc;
   __syncthreads();
-  if (t == 0) {
-    atomicAdd(counters + 1, 1);
-    while (__hip_atomic_load(counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) __builtin_amdgcn_s_sleep(2);
+  if (t < 64) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += s_part[q * 64 + t];  // ascending location group: one fixed summation order
+    g_ws[64 * g + t] = exp2f(log2f(sum / (float)npix) / p);
   }
+}
+__global__ __launch_bounds__(512) void k_ep_tail_fc(const float* __restrict__ g_ws, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                    float* __restrict__ y_ws, int* __restrict__ counters, float* __restrict__ out) {
+  __shared__ float s_g[512], s_part[512], s_red[8];
+  __shared__ int s_last;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = blockIdx.x;
+  s_g[t] = g_ws[t];  // written by the previous kernel: visible at the kernel boundary
   __syncthreads();
-  s_g[t] = __hip_atomic_load(g_ws + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // other workgroups' values: device-scope loads, not a stale L1 line
-  __syncthreads();
-  // (4) Linear: outputs [64 g, 64 g + 64); thread (part, output) covers inputs [64 part, 64 part + 64)
+  // (3) Linear: outputs [64 g, 64 g + 64); thread (part, output) covers inputs [64 part, 64 part + 64)
   const int j = 64 * g + lane, part = wave;
   float d = 0.f;
 #pragma unroll 8
@@ -316,16 +331,16 @@ __global__ __launch_bounds__(512) void k_ep_tail(const _Float16* __restrict__ fe
     float y = bias[64 * g + t];
 #pragma unroll
     for (int q = 0; q < 8; ++q) y += s_part[q * 64 + t];
-    y_ws[64 * g + t] = y;
+    __hip_atomic_store(y_ws + 64 * g + t, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // (5) last workgroup: final L2 normalisation
+  // (4) last workgroup to arrive: final L2 normalisation (a ticket, not a barrier: no workgroup ever waits for another)
   __threadfence();
   __syncthreads();
   if (t == 0) s_last = atomicAdd(counters, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
   __threadfence();
-  const float y = __hip_atomic_load(y_ws + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float y = __hip_atomic_load(y_ws + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // other workgroups' values: device-scope loads, not a stale L1 line
   const float ss = wave_sum(y * y);
   if (lane == 0) s_red[wave] = ss;
   __syncthreads();
@@ -333,12 +348,12 @@ __global__ __launch_bounds__(512) void k_ep_tail(const _Float16* __restrict__ fe
 #pragma unroll
   for (int w = 0; w < 8; ++w) tot += s_red[w];
   out[t] = y / fmaxf(sqrtf(tot), 1e-12f);
-  if (t == 0) { counters[0] = 0; counters[1] = 0; }
 }
-// ws: [1024] floats, counters: [2] ints (zero before the first call; the kernel leaves them zero)
+// ws: [1024] floats, counters: [>= 1] int (any value: the first kernel resets it).  Calls of one handle are stream-ordered (include/sship.h).
 void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* ws, int* counters, float* out,
                     hipStream_t s) {
-  hipLaunchKernelGGL(k_ep_tail, dim3(kTailWg), dim3(512), (size_t)(npix + 512 + 512 + 8) * 4, s, feat, npix, p, wt, bias, ws, counters, out);
+  hipLaunchKernelGGL(k_ep_tail_pool, dim3(kTailWg), dim3(512), (size_t)(npix + 512) * 4, s, feat, npix, p, ws, counters);
+  hipLaunchKernelGGL(k_ep_tail_fc, dim3(kTailWg), dim3(512), 0, s, ws, wt, bias, ws + 512, counters, out);
 }
 
 }  // namespace sship

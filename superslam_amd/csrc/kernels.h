@@ -90,9 +90,9 @@ hipError_t sp_conv1x1_f32(const ConvW& w, const _Float16* in, float* out, int os
                           hipStream_t s);
 
 // ---- ep_kernels.hip : EigenPlaces (ResNet-18 + GeM) ----
-// ws: split-K workspace (ep_splitk_workspace_bytes) or null = never split
+// ws: split-K workspace of ws_bytes (ep_splitk_workspace_bytes) or null = never split; the split is clamped to what fits
 hipError_t ep_conv(const ConvW& w, const _Float16* in, _Float16* out, const _Float16* res, int H, int W, bool relu, bool decim,
-                   hipStream_t s, float* ws = nullptr);
+                   hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0);
 size_t ep_splitk_workspace_bytes(int in_h, int in_w);
 void launch_ep_resize_norm(const uint8_t* src, int stride, int ch, const int* tab, int out_w, int out_h, float* out, hipStream_t s);
 void launch_ep_im2col(const float* x, int H, int W, int Ho, int Wo, _Float16* out, hipStream_t s);

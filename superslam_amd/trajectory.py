@@ -98,24 +98,55 @@ def ate(gt_poses, est_poses, align: bool = True, correct_scale: bool = False) ->
             "std": float(e.std()), "min": float(e.min()), "max": float(e.max()), "sse": float((e ** 2).sum())}
 
 
-def kitti_segments(gt_poses, est_poses) -> dict:
-    """KITTI t_rel (%) and r_rel (deg/m) averaged over all 100..800 m segments (_eval_common.py:72-111)."""
+def _rigid_inverse(T: np.ndarray) -> np.ndarray:
+    """Batched inverse of [..., 4, 4] rigid transforms: [R | t]^-1 = [R^T | -R^T t] (no general matrix inversion)."""
+    Rt = np.swapaxes(T[..., :3, :3], -1, -2)
+    out = np.zeros_like(T)
+    out[..., :3, :3] = Rt
+    out[..., :3, 3] = -np.einsum("...ij,...j->...i", Rt, T[..., :3, 3])
+    out[..., 3, 3] = 1.0
+    return out
+
+
+def kitti_segment_table(gt_poses, est_poses, lengths=KITTI_LENGTHS, step: int = KITTI_STEP) -> np.ndarray:
+    """One row ``(start frame, end frame, segment length [m], translation error [m], rotation error [rad])`` per KITTI
+    odometry sub-sequence - the table the KITTI devkit averages (evaluate_odometry: start frames every `step` frames, a
+    segment of nominal length L ends at the first frame whose driven distance from the start is >= L; starts whose
+    segment runs off the end of the sequence are dropped).
+
+    Formulation: the driven distance s[i] is monotone, so every segment end is one ``np.searchsorted(s, s[start] + L)``
+    (all starts x all lengths at once); the segment error E = (est_a^-1 est_b)^-1 (gt_a^-1 gt_b) is evaluated for all
+    segments in one batch with the closed-form rigid inverse.  Translation error = |E_t|, rotation error = the angle of E_R.
+    """
     gt, est = _as_4x4(gt_poses), _as_4x4(est_poses)
-    d = np.linalg.norm(np.diff(gt[:, :3, 3], axis=0), axis=1)
-    dist = np.concatenate([[0.0], np.cumsum(d)])
-    t_errs, r_errs = [], []
-    for first in range(0, len(gt), KITTI_STEP):
-        for length in KITTI_LENGTHS:
-            idx = np.nonzero(dist[first:] >= dist[first] + length)[0]
-            if len(idx) == 0:
-                continue
-            last = first + int(idx[0])
-            gt_rel = np.linalg.inv(gt[first]) @ gt[last]
-            est_rel = np.linalg.inv(est[first]) @ est[last]
-            err = np.linalg.inv(est_rel) @ gt_rel
-            t_errs.append(np.linalg.norm(err[:3, 3]) / length)
-            cos = (np.trace(err[:3, :3]) - 1.0) * 0.5
-            r_errs.append(np.arccos(max(-1.0, min(1.0, cos))) / length)
-    if not t_errs:
+    assert len(gt) == len(est)
+    s = np.zeros(len(gt))
+    np.cumsum(np.linalg.norm(gt[1:, :3, 3] - gt[:-1, :3, 3], axis=1), out=s[1:])
+    starts = np.arange(0, len(gt), step)
+    L = np.asarray(lengths, np.float64)
+    ends = np.searchsorted(s, s[starts, None] + L[None, :], side="left")      # [starts, lengths]; len(gt) = ran off the end
+    # searchsorted looks at the whole sequence; a segment must end at or after its start (s is non-decreasing, L > 0: it does)
+    ok = ends < len(gt)
+    a = np.broadcast_to(starts[:, None], ends.shape)[ok]
+    b = ends[ok]
+    seg_len = np.broadcast_to(L[None, :], ends.shape)[ok]
+    gt_motion = _rigid_inverse(gt[a]) @ gt[b]
+    est_motion = _rigid_inverse(est[a]) @ est[b]
+    E = _rigid_inverse(est_motion) @ gt_motion
+    t_err = np.linalg.norm(E[:, :3, 3], axis=1)
+    # rotation angle from both the trace (cos) and the antisymmetric part (sin): unlike arccos alone this keeps its
+    # precision near 0, where the metric of a good estimate lives (arccos(1 - 1e-16) is already 1.5e-8 rad)
+    Re = E[:, :3, :3]
+    sin_axis = 0.5 * np.stack([Re[:, 2, 1] - Re[:, 1, 2], Re[:, 0, 2] - Re[:, 2, 0], Re[:, 1, 0] - Re[:, 0, 1]], axis=1)
+    angle = np.arctan2(np.linalg.norm(sin_axis, axis=1), 0.5 * (np.einsum("nii->n", Re) - 1.0))
+    return np.stack([a.astype(np.float64), b.astype(np.float64), seg_len, t_err, angle], axis=1)
+
+
+def kitti_segments(gt_poses, est_poses) -> dict:
+    """KITTI t_rel (%) and r_rel (deg/m): the per-segment errors of `kitti_segment_table`, each divided by its segment's nominal
+    length, averaged over all segments of all lengths (the two figures scripts/benchmarks/_eval_common.py:88-111 reports)."""
+    tab = kitti_segment_table(gt_poses, est_poses)
+    if len(tab) == 0:
         return {"t_rel_percent": float("nan"), "r_rel_deg_per_m": float("nan")}
-    return {"t_rel_percent": float(np.mean(t_errs) * 100.0), "r_rel_deg_per_m": float(np.degrees(np.mean(r_errs)))}
+    return {"t_rel_percent": float(100.0 * np.mean(tab[:, 3] / tab[:, 2])),
+            "r_rel_deg_per_m": float(np.degrees(np.mean(tab[:, 4] / tab[:, 2])))}

@@ -1,5 +1,5 @@
-// C++ host-layer tests.  CPU part: FreeList semantics (the reference's tests/test_descriptor_pool.cc cases)
-// and "fails loudly without a device".  GPU part (argv[1] = sp weights, argv[2] = lg weights): the
+// C++ host-layer tests.  CPU part: "fails loudly without a device" (pool, extractor).  GPU part: the reference's
+// tests/test_descriptor_pool.cc cases on the C ABI's pool and (argv[1] = sp weights, argv[2] = lg weights) the
 // StereoFrontEnd consumer semantics of the reference's tests/test_stereo_frontend.cc, driven through the real
 // extractor / matcher behind the IFeatureExtractor / IFeatureMatcher interfaces.
 #include <algorithm>
@@ -15,24 +15,37 @@ using namespace superslam_hip;
 static int g_fail = 0;
 #define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
 
-static void test_freelist() {
-  {  // FreeList.AcquireReleaseRoundTrips
-    FreeList f(3);
-    const int a = f.acquire(), b = f.acquire(), c = f.acquire();
-    EXPECT(a >= 0); EXPECT(b >= 0); EXPECT(c >= 0);
-    EXPECT(f.acquire() == -1);
-    EXPECT(f.in_use() == 3);
-    f.release(b);
-    EXPECT(f.in_use() == 2);
-    EXPECT(f.acquire() == b);
+// The reference's tests/test_descriptor_pool.cc cases (FreeList.AcquireReleaseRoundTrips, FreeList.EmptyAndFull) on the
+// bookkeeping the product actually uses: the C ABI's pool (sship_pool_acquire / release / in_use).  Needs a device (the pool
+// owns device slots); without one sship_pool_create must fail loudly.
+static void test_pool_bookkeeping(bool have_device) {
+  sship_pool* p = nullptr;
+  if (!have_device) {
+    EXPECT(sship_pool_create(3, 16, 256, &p) == SSHIP_ERR_NO_DEVICE && p == nullptr);
+    EXPECT(sship_pool_acquire(nullptr) == -1 && sship_pool_in_use(nullptr) == 0);
+    return;
   }
-  {  // FreeList.EmptyAndFull
-    FreeList f(2);
-    EXPECT(f.in_use() == 0);
-    const int a = f.acquire(), b = f.acquire();
-    EXPECT(f.in_use() == 2);
-    f.release(a); f.release(b);
-    EXPECT(f.in_use() == 0);
+  {  // AcquireReleaseRoundTrips
+    EXPECT(sship_pool_create(3, 16, 256, &p) == SSHIP_OK);
+    const int a = sship_pool_acquire(p), b = sship_pool_acquire(p), c = sship_pool_acquire(p);
+    EXPECT(a >= 0); EXPECT(b >= 0); EXPECT(c >= 0);
+    EXPECT(a != b && b != c && a != c);
+    EXPECT(sship_pool_acquire(p) == -1);
+    EXPECT(sship_pool_in_use(p) == 3);
+    sship_pool_release(p, b);
+    EXPECT(sship_pool_in_use(p) == 2);
+    EXPECT(sship_pool_acquire(p) == b);   // LIFO: the slot released last is handed out first
+    EXPECT(sship_pool_slot_ptr(p, a) != nullptr && sship_pool_slot_ptr(p, 3) == nullptr);
+    sship_pool_destroy(p);
+  }
+  {  // EmptyAndFull
+    EXPECT(sship_pool_create(2, 16, 256, &p) == SSHIP_OK);
+    EXPECT(sship_pool_in_use(p) == 0);
+    const int a = sship_pool_acquire(p), b = sship_pool_acquire(p);
+    EXPECT(sship_pool_in_use(p) == 2);
+    sship_pool_release(p, a); sship_pool_release(p, b);
+    EXPECT(sship_pool_in_use(p) == 0);
+    sship_pool_destroy(p);
   }
 }
 
@@ -130,10 +143,11 @@ static int run_gpu(const char* spw, const char* lgw) {
 }
 
 int main(int argc, char** argv) {
-  test_freelist();
+  const bool have_device = sship_init(-1) == SSHIP_OK;
+  test_pool_bookkeeping(have_device);
   if (argc < 3) {
     // CPU box: the library must fail loudly, never fall back
-    if (sship_init(-1) == SSHIP_OK) { std::printf("cpp: a GPU is visible, pass weight paths to run the GPU part\n"); return g_fail ? 1 : 0; }
+    if (have_device) { std::printf("cpp: a GPU is visible, pass weight paths to run the GPU part\n"); return g_fail ? 1 : 0; }
     SuperPoint sp("missing.safetensors", 600, 0.005, 4);
     EXPECT(!sp.initialize());
     EXPECT(sp.last_error().find("no HIP device") != std::string::npos);

@@ -6,17 +6,14 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "superslam_amd", "lib", "test_host_layer")
+BIN = os.path.join(ROOT, "tests", "_build", "test_host_layer")   # test artefact: outside the package directory (git-ignored, travels to the GPU box)
 
 
-def _build():
-    libdir = os.path.join(ROOT, "superslam_amd", "lib")
-    src = os.path.join(ROOT, "tests", "cpp", "test_host_layer.cc")
-    hdr = os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp")
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
-                               "-L" + libdir, "-lsuperslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    return BIN
+def _build(sanitize=False):
+    from _cppbuild import cpp_binary
+
+    return cpp_binary("test_host_layer", [os.path.join(ROOT, "tests", "cpp", "test_host_layer.cc")],
+                      deps=[os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp"), os.path.join(ROOT, "include", "sship.h")], sanitize=sanitize)
 
 
 def test_cpp_host_layer_cpu():

@@ -13,14 +13,12 @@ BIN = os.path.join(ROOT, "superslam_amd", "lib", "frontend_benchmark")
 
 
 def _build():
-    libdir = os.path.join(ROOT, "superslam_amd", "lib")
-    src = os.path.join(ROOT, "examples", "frontend_benchmark.cc")
-    hdr = os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp")
-    hdr2 = os.path.join(ROOT, "include", "superslam_hip", "image_io.hpp")
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
-                               "-L" + libdir, "-lsuperslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-lz"])
-    return BIN
+    from _cppbuild import LIBDIR, cpp_binary
+
+    # the per-frame benchmark runner is an example PRODUCT binary (examples/): it lives next to the library
+    return cpp_binary("frontend_benchmark", [os.path.join(ROOT, "examples", "frontend_benchmark.cc")],
+                      deps=[os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp"), os.path.join(ROOT, "include", "superslam_hip", "image_io.hpp")],
+                      extra=["-lpthread", "-lz"], opt="-O2", outdir=LIBDIR)
 
 
 def test_benchmark_runner_builds_and_rejects_bad_usage():
@@ -133,13 +131,11 @@ def write_png(path, img, filter_type=None, color=False, sixteen=False):
                 + chunk(b"IEND", b""))
 
 
-def _build_io_test():
-    binp = os.path.join(ROOT, "superslam_amd", "lib", "test_image_io")
-    src = os.path.join(ROOT, "tests", "cpp", "test_image_io.cc")
-    hdr = os.path.join(ROOT, "include", "superslam_hip", "image_io.hpp")
-    if not os.path.exists(binp) or os.path.getmtime(binp) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", binp, "-lz"])
-    return binp
+def _build_io_test(sanitize=False):
+    from _cppbuild import cpp_binary
+
+    return cpp_binary("test_image_io", [os.path.join(ROOT, "tests", "cpp", "test_image_io.cc")],
+                      deps=[os.path.join(ROOT, "include", "superslam_hip", "image_io.hpp")], link_lib=False, extra=["-lz"], sanitize=sanitize)
 
 
 def test_png_and_pgm_decoders_bit_exact(tmp_path):

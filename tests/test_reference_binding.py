@@ -9,23 +9,20 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-BIN = os.path.join(ROOT, "superslam_amd", "lib", "test_reference_binding")
+BIN = os.path.join(ROOT, "tests", "_build", "test_reference_binding")   # test artefact: outside the package directory (git-ignored, travels to the GPU box)
 
 
-def build(force=False):
-    libdir = os.path.join(ROOT, "superslam_amd", "lib")
+def build(force=False, sanitize=False):
+    from _cppbuild import cpp_binary
+
     srcs = [os.path.join(ROOT, "tests", "cpp", "test_reference_binding.cc"), os.path.join(REF, "src", "StereoFrontEnd.cc"),
             os.path.join(REF, "src", "PlaceRecognizer.cc")]   # the adapter holds the reference's own CosineDescriptorIndex
     deps = srcs + [os.path.join(ROOT, "integration", "reference_side", f) for f in ("SuperPoint.h", "LightGlue.h", "EigenPlaces.h")] + \
         [os.path.join(ROOT, "include", "superslam_hip", "frontend.hpp"), os.path.join(ROOT, "tests", "cpp", "shim", "opencv4", "opencv2", "core.hpp")]
-    if force or not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function",
-                               "-I" + os.path.join(ROOT, "integration", "reference_side"),   # SuperPoint.h / LightGlue.h resolve to the adapters
-                               "-I" + os.path.join(ROOT, "tests", "cpp", "shim"),
-                               "-I" + os.path.join(REF, "include"),                          # everything else: the reference's own headers
-                               "-I" + os.path.join(ROOT, "include"), *srcs, "-o", BIN,
-                               "-L" + libdir, "-lsuperslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    return BIN
+    return cpp_binary("test_reference_binding", srcs, deps=deps, force=force, sanitize=sanitize, extra=["-Wno-unused-function"],
+                      includes=[os.path.join(ROOT, "integration", "reference_side"),   # SuperPoint.h / LightGlue.h resolve to the adapters
+                                os.path.join(ROOT, "tests", "cpp", "shim"),
+                                os.path.join(REF, "include")])                          # everything else: the reference's own headers
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists only in the build container")
@@ -43,7 +40,7 @@ def test_binding_compiles_against_the_reference_headers_and_passes_cpu_cases():
 def test_binding_runs_the_reference_front_end_on_the_gpu(weights_dir):
     if not os.path.exists(BIN):
         if not os.path.isdir(REF):
-            pytest.fail("superslam_amd/lib/test_reference_binding is missing: __graft_entry__.build() produces it in the build container")
+            pytest.fail("tests/_build/test_reference_binding is missing: __graft_entry__.build() produces it in the build container")
         build()
     from superslam_amd.weights import make_eigenplaces_weights, save_safetensors
 
