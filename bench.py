@@ -27,6 +27,10 @@ Prints ONE JSON line with the driver's fields plus
   n1024         : the same metric with 1024 keypoints per image (the reference engine's upper profile)
   end_to_end    : the same step with the u8 images uploaded from pinned host memory (double buffered) and keypoints /
                   matches copied back inside the timed region (PCIe-inclusive; never `value`)
+  power         : socket watts / shader MHz sampled by a poller thread (scripts/power_telemetry.py, >= 20 Hz) DURING the timed steps:
+                  {avg_W, cap_W, sclk_MHz, joules_per_pair, pairs_per_s_at_cap}; every matrix kernel of the call runs on the board's power
+                  cap, so joules per pair is the unit kernel work is priced in; `joules_per_launch` on every roofline_mfma / roofline_hbm row
+                  comes from a >= 0.6 s loop of that stage under the same poller (rank 0; --no-power switches it off)
   cpu_baseline  : the CPU oracle (kind "port") on this box's host cores, bounded sample, rank 0 at N = 1 only.
 --headline-only runs the warm-up and the timed steps and nothing else (profiling passes: every launch is a headline launch).
 """
@@ -312,6 +316,9 @@ def main():
                          "(scripts/pmc_traffic.sh, ~20-60 s, 150 s limit; needs rocprofv3 on PATH).  On any failure the figure is READ from "
                          "profiles/pmc_conv1ab.json instead and traffic_source says so")
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
+    ap.add_argument("--no-power", action="store_true", help="do not sample socket power / shader clock (scripts/power_telemetry.py)")
+    ap.add_argument("--power-dump", default=None, help="write the poller's raw (t, W, MHz) samples + the stamps of the timed region to this JSON file")
+    ap.add_argument("--stage-energy-s", type=float, default=0.6, help="seconds each isolated stage loops under the power poller (0 = skip the per-stage joules)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: re-execute as N ranks under torch.distributed.run (does not return then)
@@ -365,6 +372,15 @@ def main():
         for x in chunks:
             fe.run(x, stream)
 
+    # socket power / shader clock of rank 0's GPU, sampled by a thread while the steps run (reads of a sysfs file; the timed region itself
+    # is untouched: same calls, same synchronisation)
+    poller = None
+    if rank == 0 and not args.no_power:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import power_telemetry
+
+        poller = power_telemetry.PowerPoller(local_rank, hz=50.0)
+        poller.__enter__()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -372,6 +388,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    tm0 = time.monotonic()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
@@ -379,6 +396,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tm1 = time.monotonic()
     dt_own = dt
     if use_dist:
         dt = all_reduce_max_seconds(dt)   # the slowest rank defines the step time
@@ -414,9 +432,28 @@ def main():
         }
         if scale is not None:
             out["scale_extras"] = scale
+        if poller is not None:
+            import power_telemetry
+
+            # this rank's GPU over the timed steps (the first 10 % of the window is dropped: the SMU's figure is a short moving average)
+            pw = poller.window(tm0, tm1, settle_s=0.1 * (tm1 - tm0)) if poller.ok else None
+            blk = power_telemetry.energy_block(pw, poller.cap_w, P * CH * args.steps / dt_own, "pair")
+            if blk is not None:
+                blk["backend"] = poller.backend.name
+                blk["window"] = "the timed steps of rank 0's GPU (first 10 % dropped)"
+                blk["value_over_pairs_per_s_at_cap"] = round((P * CH * args.steps / dt_own) / blk["pairs_per_s_at_cap"], 4) if blk.get("pairs_per_s_at_cap") else None
+                out["power"] = blk
+            else:
+                out["power"] = {"error": "no power telemetry backend answered on this box (sysfs hwmon, librocm_smi64, rocm-smi)"}
         if not args.headline_only:
             out["self_check"] = self_check(torch, np, fe, chunks[CH - 1], stream, wdir, args.max_kp)
-            extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, world, spw, lgw, pairs)
+            extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, world, spw, lgw, pairs, poller)
+        if poller is not None:
+            poller.__exit__(None, None, None)
+            if args.power_dump and poller.ok:
+                with open(args.power_dump, "w") as f:
+                    json.dump({"backend": poller.backend.name, "cap_W": poller.cap_w, "timed_region": [tm0, tm1], "pairs_timed": P * CH * args.steps,
+                               "samples": [[round(t, 4), w, c] for (t, w, c) in poller.samples]}, f)
         print(json.dumps(out), flush=True)
         if not args.headline_only and not out["self_check"]["ok"]:
             sp.close(); lg.close()
@@ -427,7 +464,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, world, spw, lgw, pairs):
+def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, world, spw, lgw, pairs, poller=None):
     """Everything next to the headline number (rank 0): per-stage times, rooflines, N = 1024, PCIe-inclusive variant, latency,
     the deployed unit, CPU baseline.  All after the timed region."""
     from superslam_amd import FrontEndBatch, LightGlue, SuperPoint, _lib
@@ -681,6 +718,52 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     # matrix pipe + VALU (it is priced in roofline_mfma as lg_assign_pass1 / pass2); the entry above is kept for its byte counts
     hbm[-1]["bound"] = "mfma+valu (by design: 11x the algorithmic bytes are re-read from L2 instead of a 92 MB fp32 matrix going through HBM four times)"
     out["roofline_hbm"] = hbm
+
+    # ---- joules per launch: every stage loops for >= --stage-energy-s seconds under the poller; energy = mean socket power x launch time ----
+    # (gross socket power, idle floor included - the same convention as `power.joules_per_pair`, so the rows add up to the call)
+    if poller is not None and poller.ok and args.stage_energy_s > 0:
+        def stage_energy(run_iters, ms_guess):
+            iters = max(10, int(args.stage_energy_s * 1e3 / max(ms_guess, 1e-3)))
+            ta = time.monotonic()
+            ms = run_iters(iters)
+            tb = time.monotonic()
+            w = poller.window(ta, tb, settle_s=0.25 * (tb - ta))
+            if not w:
+                return None
+            return {"joules_per_launch": round(w["avg_W"] * ms * 1e-3, 5), "avg_W": w["avg_W"], "sclk_MHz": w["sclk_MHz"],
+                    "launch_ms_energy_loop": round(ms, 4), "samples": w["n"]}
+
+        sp_ids = {name: lid for lid, name in enumerate(names)}
+        lg_ids = {name: sid for sid, name in enumerate(lg_flops)}
+        for row in out["roofline_mfma"]:
+            k = row["kernel"]
+            e = None
+            if k in sp_ids:
+                e = stage_energy(lambda it, lid=sp_ids[k]: sp_layer(lid, it)[0], row.get("launch_ms_isolated", row["launch_ms"]))
+            elif k in lg_ids:
+                e = stage_energy(lambda it, sid=lg_ids[k]: lg_stage(sid, it), row["launch_ms"])
+            if e:
+                row.update(e)
+        for row, lid in ((hbm[0], 12), (hbm[2], 13), (hbm[3], 14)):
+            e = stage_energy(lambda it, lid=lid: sp_layer(lid, it)[0], row["launch_ms"])
+            if e:
+                row.update(e)
+        e = stage_energy(lambda it: sp_layer(9, it)[0], hbm[1]["launch_ms"])
+        if e:
+            hbm[1].update(e)
+        # the call's joule budget from its launches (one 64-pair call = the SuperPoint launches once + the LightGlue stage mix), next to the
+        # figure measured over the timed steps: they agree when nothing but these launches draws power
+        per = {r["kernel"]: r.get("joules_per_launch") for r in out["roofline_mfma"] + hbm}
+        if all(per.get(k) is not None for k in ("conv1a+conv1b+pool", "lg_self_attention", "lg_self_ffn+to_qk|to_v")):
+            sp_j = sum(per[k] for k in ("conv1a+conv1b+pool", "conv2a", "conv2b+pool", "conv3a", "conv3b+pool", "conv4a", "conv4b", "convPa") if per.get(k))
+            sp_j += sum(v for k, v in per.items() if v and k.startswith(("k_nms_tile", "k_convpb_stream", "k_topk", "k_desc_head_sparse")))
+            lg_j = (per["lg_wqkv0_proj"] + 9 * per["lg_self_attention"] + 9 * per["lg_cross_attention"] + 9 * per["lg_self_ffn+to_qk|to_v"]
+                    + 8 * per["lg_cross_ffn+wqkv"] + per["lg_last_ffn+final_proj"] + per["lg_assign_pass1_lse"] + per["lg_assign_pass2_argmax"])
+            out["joule_budget_per_call"] = {"superpoint_J": round(sp_j, 3), "lightglue_J": round(lg_j, 3), "sum_J": round(sp_j + lg_j, 3),
+                                            "per_pair_J": round((sp_j + lg_j) / P, 5),
+                                            "measured_over_timed_steps_per_pair_J": out.get("power", {}).get("joules_per_pair"),
+                                            "note": "sum over the call's launches of (mean socket power of that stage looping alone) x (its launch time); the two "
+                                                    "half-batch streams of the LightGlue call overlap in time, not in joules"}
 
     lat_probe("after_hbm_stages")
     # ---- N = 1024 keypoints per image (the reference engine's upper profile; SURVEY 8(d) config 2 second run) ----

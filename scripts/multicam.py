@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--max-kp", type=int, default=1024)
     ap.add_argument("--ticks", type=int, default=20)
     ap.add_argument("--gpus", type=int, default=1, help="N > 1 without a launcher: re-executes under torch.distributed.run with N ranks")
+    ap.add_argument("--dump", default=None, help="every rank writes <dump>.rank<r>.npz: its pair list, matches0 / mscores0 of the last tick and the "
+                                                  "gathered (desc, kp, n) - tests/test_gpu_configs_at_size.py checks BASELINE.md 4 row 5 with it")
     args = ap.parse_args()
     from superslam_amd.shard import relaunch_under_launcher_if_needed
     relaunch_under_launcher_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -78,6 +80,14 @@ def main():
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if args.dump:
+        desc, kp, n = sp.extract_batch_device(cams)
+        gd, gk, gn = all_gather_features(desc, kp, n, args.cameras) if use_dist else (desc, kp, n)
+        torch.cuda.synchronize()
+        np.savez(f"{args.dump}.rank{rank}.npz", pairs=np.asarray(my_pairs, np.int32).reshape(-1, 2),
+                 m0=out[0].cpu().numpy() if out is not None else np.zeros((0, k), np.int32),
+                 ms0=out[1].cpu().numpy() if out is not None else np.zeros((0, k), np.float32),
+                 desc=gd.cpu().numpy(), kp=gk.cpu().numpy(), n=gn.cpu().numpy())
     if rank == 0:
         m0 = out[0] if out is not None else None
         print(json.dumps({"cameras": args.cameras, "ranks": world, "pairs_total": args.cameras * (args.cameras - 1) // 2,

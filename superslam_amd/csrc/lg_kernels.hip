@@ -287,21 +287,25 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   // one key tile for the QT query tiles of this wave
   // V = 3: the QK^T chains of ALL query tiles are issued first, interleaved k-step by k-step (independent accumulators: no
   // dependent-MFMA stall, and the second tile's MFMAs execute while the first tile's softmax VALU issues); V <= 2: tile by tile.
-  auto tile = [&](const h8_t (&kf)[4], const h8_t (&vf)[2][2], int kt) __attribute__((always_inline)) {
+  // NT = the query tiles of this unit that really exist (round 6): 19 query tiles at 600 keypoints are nine units of two tiles and ONE of a
+  // single tile - its second tile used to be computed over all key tiles from a clamped address and thrown away at the store (1 / 20 of the
+  // launch's MFMAs, exponentials and joules).  The same holds for any image with fewer keypoints than capacity.
+  auto tile = [&](auto ntc, const h8_t (&kf)[4], const h8_t (&vf)[2][2], int kt) __attribute__((always_inline)) {
+    constexpr int NT = decltype(ntc)::value;
     const int k0 = kt * 32;
     const f16x_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f16x_t stq[QT];
+    f16x_t stq[NT];
     if constexpr (V == 3) {
 #pragma unroll
-      for (int t = 0; t < QT; ++t) stq[t] = mfma32_attn(ones_k0, rf[t], zero16);
+      for (int t = 0; t < NT; ++t) stq[t] = mfma32_attn(ones_k0, rf[t], zero16);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int t = 0; t < QT; ++t) stq[t] = mfma32_attn(kf[ks], qf[t][ks], stq[t]);
+        for (int t = 0; t < NT; ++t) stq[t] = mfma32_attn(kf[ks], qf[t][ks], stq[t]);
       __builtin_amdgcn_sched_barrier(0);  // the MFMAs above stay ahead of the first tile's softmax
     }
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
+    for (int t = 0; t < NT; ++t) {
       f16x_t st;
       if constexpr (V == 3) st = stq[t];
       else {
@@ -381,16 +385,21 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
   };
   fetch(kfA, vfA, ksp);
   if (SSHIP_ATTN_TRACE_BUILD && trace) tr1 = __builtin_readcyclecounter();
-  for (int kt = ksp; kt < ntiles; kt += 2 * KS) {
-    fetch(kfB, vfB, kt + KS);
-    __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above this tile's MFMAs / softmax
-    tile(kfA, vfA, kt);
-    if (kt + KS < ntiles) {
-      fetch(kfA, vfA, kt + 2 * KS);
-      __builtin_amdgcn_sched_barrier(0);
-      tile(kfB, vfB, kt + KS);
+  auto key_loop = [&](auto ntc) __attribute__((always_inline)) {
+    for (int kt = ksp; kt < ntiles; kt += 2 * KS) {
+      fetch(kfB, vfB, kt + KS);
+      __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above this tile's MFMAs / softmax
+      tile(ntc, kfA, vfA, kt);
+      if (kt + KS < ntiles) {
+        fetch(kfA, vfA, kt + 2 * KS);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(ntc, kfB, vfB, kt + KS);
+      }
     }
-  }
+  };
+  // wave-uniform: the unit's live query tiles (the tiles past nq keep l = 0, o = 0 and are never stored: the store loops break at nq)
+  if (QT == 1 || q0 + 32 * (QT - 1) < nq) key_loop(std::integral_constant<int, QT>{});
+  else key_loop(std::integral_constant<int, 1>{});
   if (SSHIP_ATTN_TRACE_BUILD && trace) tr2 = __builtin_readcyclecounter();
   if constexpr (KS == 1 && SSHIP_ATTN_REGFIN) {
     // no key split: nothing to merge - every lane normalises and stores its own accumulators (same values, same stores as the

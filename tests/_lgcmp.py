@@ -33,7 +33,7 @@ MIN_MARGIN = 1.25
 # entries of the parity report that compare two fp16 paths with each other (everything else with an mscores figure is path vs oracle)
 PATH_VS_PATH_ENTRIES = {"batch128_vs_per_frame": "mscores_maxd", "lg_batch64_vs_single": "mscores_maxd", "bench_self_check": "mscores_maxd",
                         "lg_translation_invariance": "mscores_maxd", "lg_permutation_equivariance": "mscores_maxd",
-                        "lg_ffn_kernel_variants": "mscores_maxd"}
+                        "lg_ffn_kernel_variants": "mscores_maxd", "config4_multicam_at_size": "mscores_maxd_one_pair_vs_batch"}
 
 
 def compare(m, s, m_ref, s_ref, bar=PATH_VS_ORACLE_BAR):
