@@ -316,6 +316,8 @@ def main():
                          "(scripts/pmc_traffic.sh, ~20-60 s, 150 s limit; needs rocprofv3 on PATH).  On any failure the figure is READ from "
                          "profiles/pmc_conv1ab.json instead and traffic_source says so")
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
+    ap.add_argument("--library", default=None, help="developer A/B: load this build of the C-ABI library instead of the shipped one (explicit; the "
+                                                    "package reads no environment variable for it).  The JSON line records it")
     ap.add_argument("--no-power", action="store_true", help="do not sample socket power / shader clock (scripts/power_telemetry.py)")
     ap.add_argument("--power-dump", default=None, help="write the poller's raw (t, W, MHz) samples + the stamps of the timed region to this JSON file")
     ap.add_argument("--stage-energy-s", type=float, default=0.6, help="seconds each isolated stage loops under the power poller (0 = skip the per-stage joules)")
@@ -333,6 +335,7 @@ def main():
     from superslam_amd.synth import make_stereo_pair
     from superslam_amd.weights import make_lightglue_weights, make_superpoint_weights, save_safetensors
 
+    _lib.set_library_path(args.library)   # None: the shipped superslam_amd/lib/libsuperslam_hip.so
     from superslam_amd.shard import all_reduce_max_seconds, dist_env, init_process_group
 
     rank, local_rank, world, under_launcher, backend = dist_env()   # local_rank = this rank's device (LOCAL_RANK unless pinned)
@@ -430,6 +433,8 @@ def main():
             "executed_tflops": round(value * executed_flops_per_pair(H, W, args.max_kp) / 1e12, 2),
             "executed_frac_of_mfma_peak": round(value * executed_flops_per_pair(H, W, args.max_kp) / 1e12 / MFMA_PEAK_TFLOPS, 4),
         }
+        if args.library:
+            out["library"] = "DEVELOPER BUILD " + os.path.relpath(_lib.LIB_PATH, ROOT) + " (not the shipped library: not a headline number)"
         if scale is not None:
             out["scale_extras"] = scale
         if poller is not None:

@@ -13,12 +13,14 @@
 #include <vector>
 
 #include "Logging.h"
+#include "SshipLogForward.h"   // library log callback -> SLOG_* (include/Logging.h:21-26)
 #include "PlaceRecognizer.h"  // the reference's own header (unchanged): superslam::IPlaceRecognizer, LoopCandidate
 #include "superslam_hip/place_recognizer.hpp"
 
 class EigenPlaces : public superslam::IPlaceRecognizer {
 public:
   EigenPlaces(const std::string& engine_file, int input_width, int input_height) : impl_(engine_file, input_width, input_height) {
+    superslam_hip_adapter::install_log_forwarding();
     if (const char* s = std::getenv("SUPERSLAM_LOOP_MIN_SCORE")) min_score_ = static_cast<float>(std::atof(s));  // src/EigenPlaces.cc:33-34
   }
   bool initialize() {

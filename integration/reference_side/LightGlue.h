@@ -11,6 +11,7 @@
 
 #include "InferenceInterfaces.h"  // MatchResult, superslam::IFeatureMatcher (the reference's own header)
 #include "Logging.h"
+#include "SshipLogForward.h"   // library log callback -> SLOG_* (include/Logging.h:21-26)
 #include "superslam_hip/frontend.hpp"
 
 typedef superslam_hip::LightGlueEngine LightGlueEngine;  // shareable weights (one load, many matchers)
@@ -18,9 +19,9 @@ typedef superslam_hip::LightGlueEngine LightGlueEngine;  // shareable weights (o
 class LightGlue : public superslam::IFeatureMatcher {
 public:
   explicit LightGlue(const std::string& engine_file, int image_width, int image_height)
-      : impl_(engine_file, image_width, image_height) {}
+      : impl_(engine_file, image_width, image_height) { superslam_hip_adapter::install_log_forwarding(); }
   LightGlue(std::shared_ptr<LightGlueEngine> shared_engine, int image_width, int image_height)
-      : impl_(std::move(shared_engine), image_width, image_height) {}
+      : impl_(std::move(shared_engine), image_width, image_height) { superslam_hip_adapter::install_log_forwarding(); }
   bool initialize() {
     const bool ok = impl_.initialize();
     if (!ok) SLOG_ERROR("LightGlue(HIP): {}", impl_.last_error());

@@ -15,6 +15,7 @@
 #include "DescriptorPool.h"       // the reference's own header (unchanged): superslam::DeviceDescriptors
 #include "InferenceInterfaces.h"  // the reference's own header (unchanged): IFeatureExtractor, Features
 #include "Logging.h"
+#include "SshipLogForward.h"   // library log callback -> SLOG_* (include/Logging.h:21-26)
 #include "Profiling.h"
 #include "superslam_hip/frontend.hpp"
 
@@ -63,7 +64,7 @@ inline superslam::Features to_ref(superslam_hip::Features&& f) {
 class SuperPoint : public superslam::IFeatureExtractor {
 public:
   explicit SuperPoint(const std::string& engine_file, int max_keypoints, double keypoint_threshold, int remove_borders)
-      : impl_(engine_file, max_keypoints, keypoint_threshold, remove_borders) {}
+      : impl_(engine_file, max_keypoints, keypoint_threshold, remove_borders) { superslam_hip_adapter::install_log_forwarding(); }
   bool initialize() {
     const bool ok = impl_.initialize();
     if (!ok) SLOG_ERROR("SuperPoint(HIP): {}", impl_.last_error());

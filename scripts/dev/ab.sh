@@ -15,7 +15,7 @@ for spec in "$@"; do
   tag=${spec%%=*}; rest=${spec#*=}; lib=${rest%%,*}; envs=""; [ "$rest" != "$lib" ] && envs=$(echo "${rest#*,}" | tr ',' ' ')
   case $lib in default) so=$R/superslam_amd/lib/libsuperslam_hip.so;; *) so=$R/superslam_amd/lib/variants/$lib.so;; esac
   if [ $first = 1 ]; then extra="--save /tmp/ab_ref.npz"; first=0; else extra="--ref /tmp/ab_ref.npz"; fi
-  env SUPERSLAM_HIP_LIBRARY=$so $envs python scripts/dev/lg_ab.py --pairs $P --kp $K --tag $tag $extra 2>/dev/null | tail -1 >> $O/lg_ab.jsonl
+  env SSHIP_DEV_LIBRARY=$so $envs python scripts/dev/lg_ab.py --pairs $P --kp $K --tag $tag $extra 2>/dev/null | tail -1 >> $O/lg_ab.jsonl
 done
 python - <<'PY'
 import json

@@ -14,7 +14,7 @@ O=gpurun_out/energy_abl_$ST.txt
 run() { tag=$1; shift; bash scripts/dev/power_poll.sh $tag "$@" >> $O 2>&1; tail -1 /tmp/pp_$tag.log | sed "s/^/$tag /" >> $O; }
 run base python scripts/dev/loop_kernel.py $ST
 for v in "$@"; do
-  SUPERSLAM_HIP_LIBRARY=$(pwd)/superslam_amd/lib/variants/$PFX$v.so run abl$v python scripts/dev/loop_kernel.py $ST
+  SSHIP_DEV_LIBRARY=$(pwd)/superslam_amd/lib/variants/$PFX$v.so run abl$v python scripts/dev/loop_kernel.py $ST
 done
 python - $O <<'PY'
 import re, sys

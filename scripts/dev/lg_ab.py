@@ -31,6 +31,7 @@ def main():
     import numpy as np
     import torch
 
+    sys.path.insert(0, os.path.join(ROOT, "scripts")); import _devlib; _devlib.use_dev_library()  # SSHIP_DEV_LIBRARY -> explicit set_library_path
     from superslam_amd import LightGlue, _lib
     from superslam_amd.weights import make_lightglue_weights, save_safetensors
 

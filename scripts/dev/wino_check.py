@@ -4,6 +4,7 @@ import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import torch.nn.functional as F
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')); import _devlib; _devlib.use_dev_library()  # SSHIP_DEV_LIBRARY -> explicit set_library_path (A/B builds)
 from superslam_amd import SuperPoint, _lib
 from superslam_amd.synth import make_stereo_pair
 from superslam_amd.weights import make_superpoint_weights, save_safetensors

@@ -8,6 +8,7 @@ import tempfile
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '.')); import _devlib; _devlib.use_dev_library()  # SSHIP_DEV_LIBRARY -> explicit set_library_path (A/B builds)
 from superslam_amd import LightGlue, _lib  # noqa: E402
 from superslam_amd.weights import make_lightglue_weights, save_safetensors  # noqa: E402
 

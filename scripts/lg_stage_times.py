@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the LightGlue stages (sship_lg_bench_stage) for a 64-pair batch of 600 keypoints: one line per stage.
-usage: [SUPERSLAM_HIP_LIBRARY=variant.so] python scripts/lg_stage_times.py [pairs] [max_kp]"""
+usage: [SSHIP_DEV_LIBRARY=variant.so] python scripts/lg_stage_times.py [pairs] [max_kp]"""
 import ctypes as C
 import os
 import sys
@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '.')); import _devlib; _devlib.use_dev_library()  # SSHIP_DEV_LIBRARY -> explicit set_library_path (A/B builds)
 from superslam_amd import LightGlue, _lib  # noqa: E402
 from superslam_amd.weights import make_lightglue_weights, save_safetensors  # noqa: E402
 
@@ -32,4 +33,4 @@ for sid, name in enumerate(names):
     ms = C.c_float(0)
     _lib.check(_lib.lib().sship_lg_bench_stage(lg._h, sid, 20, C.byref(ms)))
     out.append(f"{name}={ms.value * 1e3:.1f}us")
-print(os.environ.get("SUPERSLAM_HIP_LIBRARY", "default").split("/")[-1], " ".join(out), flush=True)
+print(os.environ.get("SSHIP_DEV_LIBRARY", "default").split("/")[-1], " ".join(out), flush=True)

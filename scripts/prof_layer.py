@@ -3,6 +3,7 @@ usage: prof_layer.py <layer[,layer...]> [iters] [batch]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '.')); import _devlib; _devlib.use_dev_library()  # SSHIP_DEV_LIBRARY -> explicit set_library_path (A/B builds)
 from superslam_amd import SuperPoint, _lib
 from superslam_amd.weights import make_superpoint_weights, save_safetensors
 layers = [int(x) for x in sys.argv[1].split(",")]; iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5; B = int(sys.argv[3]) if len(sys.argv) > 3 else 16

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times every SuperPoint layer (sship_sp_bench_layer) at the headline shape: one line.  usage: [SUPERSLAM_HIP_LIBRARY=...] python scripts/sp_layer_times.py [pairs]"""
+"""Times every SuperPoint layer (sship_sp_bench_layer) at the headline shape: one line.  usage: [SSHIP_DEV_LIBRARY=...] python scripts/sp_layer_times.py [pairs]"""
 import ctypes as C
 import os
 import sys
@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '.')); import _devlib; _devlib.use_dev_library()  # SSHIP_DEV_LIBRARY -> explicit set_library_path (A/B builds)
 from superslam_amd import SuperPoint, _lib  # noqa: E402
 from superslam_amd.synth import make_stereo_pair  # noqa: E402
 from superslam_amd.weights import make_superpoint_weights, save_safetensors  # noqa: E402
@@ -35,4 +36,4 @@ for lid, name in enumerate(names):
     ms = C.c_float(0)
     _lib.check(_lib.lib().sship_sp_bench_layer(sp._h, lid, 2 * P, H, W, 10, C.byref(ms), None))
     out.append(f"{name}={ms.value * 1e3:.0f}")
-print(os.environ.get("SUPERSLAM_HIP_LIBRARY", "default").split("/")[-1], " ".join(out), "(us)", flush=True)
+print(os.environ.get("SSHIP_DEV_LIBRARY", "default").split("/")[-1], " ".join(out), "(us)", flush=True)

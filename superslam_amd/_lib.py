@@ -9,8 +9,22 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SUPERSLAM_HIP_LIBRARY: developer override (A/B builds of the same ABI, see build.build_variant)
-LIB_PATH = os.environ.get("SUPERSLAM_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsuperslam_hip.so")
+# The ONE library this package loads.  No environment variable moves it (include/sship.h, "Environment": the product reads
+# SUPERSLAM_HIP_DEVICE and SSHIP_RCCL_LIBRARY, nothing else); a developer A/B build of the same ABI is selected explicitly, in code, with
+# set_library_path() before the first call (tests/test_gpu_alt_paths.py and scripts/dev/* do that through scripts/_devlib.py).
+LIB_PATH = os.path.join(_HERE, "lib", "libsuperslam_hip.so")
+
+
+def set_library_path(path) -> None:
+    """Load `path` instead of the shipped library (developer A/B builds: build.build_variant / build_dev).  None = keep the shipped one.
+    Must come before the first call into the library: one process, one library."""
+    global LIB_PATH
+    if not path:
+        return
+    path = os.path.abspath(path)
+    if _lib is not None and path != LIB_PATH:
+        raise SshipError(ERR_INVALID, f"set_library_path({path}): {LIB_PATH} is already loaded in this process")
+    LIB_PATH = path
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_IO, ERR_NOMEM, ERR_POOL_EXHAUSTED, ERR_NO_DEVICE = 1, 2, 3, 4, 5, 6

@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libsuperslam_hip.so")
 SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_pp.hip", "conv_pp128.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
 # Developer build (lib/variants/dev.so, -DSSHIP_DEV_SWITCHES=1): the same sources with the A/B switches and phase traces compiled in, plus
 # the rejected kernels they select: the lock-step strip conv (r01), Winograd conv2a/2b (r04: -25 %), the 16-wave FFN (r04: +-0), the
-# LDS-resident-key attention (r05: -8 %).  tests/test_gpu_alt_paths.py and scripts/dev/* load it through SUPERSLAM_HIP_LIBRARY.
+# LDS-resident-key attention (r05: -8 %).  tests/test_gpu_alt_paths.py and scripts/dev/* load it explicitly (superslam_amd._lib.set_library_path via scripts/_devlib.py).
 DEV_SOURCES = SOURCES + ["conv_strip.hip", "conv_wino.hip", "lg_ffn16.hip", "lg_attn_res.hip"]
 DEV_FLAGS = ["-DSSHIP_DEV_SWITCHES=1"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -79,7 +79,7 @@ def build_dev(force: bool = False) -> str:
 
 
 def build_variant(name: str, extra_flags) -> str:
-    """Developer A/B builds: same sources + extra -D flags -> lib/variants/<name>.so (load via SUPERSLAM_HIP_LIBRARY)."""
+    """Developer A/B builds: same sources + extra -D flags -> lib/variants/<name>.so (load with superslam_amd._lib.set_library_path / bench.py --library / SSHIP_DEV_LIBRARY in the dev scripts)."""
     vdir = os.path.join(LIBDIR, "variants")
     odir = os.path.join(vdir, "obj_" + name)
     os.makedirs(odir, exist_ok=True)

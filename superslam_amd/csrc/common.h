@@ -21,7 +21,7 @@ constexpr int kWave = 64;
 // Developer A/B switches.  The DEFAULT library reads exactly the environment variables documented in include/sship.h ("Environment":
 // SUPERSLAM_HIP_DEVICE, SSHIP_RCCL_LIBRARY) and runs one kernel per layer; every other switch (kernel selection, phase traces) and every
 // rejected kernel exists only in the developer build  `python -m superslam_amd.build --variant dev -DSSHIP_DEV_SWITCHES=1`
-// (superslam_amd/lib/variants/dev.so, loaded with SUPERSLAM_HIP_LIBRARY by tests/test_gpu_alt_paths.py and scripts/dev/*): there
+// (superslam_amd/lib/variants/dev.so, loaded explicitly - superslam_amd._lib.set_library_path - by tests/test_gpu_alt_paths.py and scripts/dev/*): there
 // dev_env() is getenv(), here it is a constant null and the branches behind it fold away.
 #ifndef SSHIP_DEV_SWITCHES
 #define SSHIP_DEV_SWITCHES 0

@@ -1,5 +1,5 @@
-// Minimal stand-in for spdlog (tests/cpp/shim/README.md): every level prints the raw format string to stderr, followed by
-// the string-like arguments (enough to see WHICH profile label a "[profile] {:22s} ..." line of include/Profiling.h carries).
+// Minimal stand-in for spdlog (tests/cpp/shim/README.md): every level from info up prints the raw format string to stderr, followed by
+// the string-like and numeric arguments (enough to see WHICH profile label a "[profile] {:22s} ..." line of include/Profiling.h carries).
 #pragma once
 #include <cstdio>
 #include <memory>
@@ -21,8 +21,17 @@ public:
     (detail::put_arg(a), ...);
     std::fprintf(stderr, "\n");
   }
-  template <class... A> void warn(const std::string& f, A&&...) { std::fprintf(stderr, "[warn] %s\n", f.c_str()); }
-  template <class... A> void error(const std::string& f, A&&...) { std::fprintf(stderr, "[error] %s\n", f.c_str()); }
-  template <class... A> void critical(const std::string& f, A&&...) { std::fprintf(stderr, "[critical] %s\n", f.c_str()); }
+  template <class... A> void warn(const std::string& f, A&&... a) { put("[warn] ", f, a...); }
+  template <class... A> void error(const std::string& f, A&&... a) { put("[error] ", f, a...); }
+  template <class... A> void critical(const std::string& f, A&&... a) { put("[critical] ", f, a...); }
+
+private:
+  template <class... A> static void put(const char* lvl, const std::string& f, const A&... a) {
+    std::fprintf(stderr, "%s%s", lvl, f.c_str());
+    (detail::put_arg(a), ...);
+    std::fprintf(stderr, "\n");
+  }
+
+public:
 };
 }  // namespace spdlog

@@ -144,3 +144,24 @@ def test_single_collective_record_packing_round_trips():
     d2, k2, n2 = _unpack_units(buf, db, kb, 7, desc.dtype, kp.dtype, n.dtype)
     assert torch.equal(d2[:3], desc) and torch.equal(k2[:3], kp) and torch.equal(n2[:3], n)
     assert int(n2[3:].abs().sum()) == 0 and float(d2[3:].abs().sum()) == 0.0
+
+
+def test_python_layer_has_no_environment_override_of_the_library():
+    """SUPERSLAM_HIP_LIBRARY used to swap the whole .so behind the package's back.  The package now loads ONE path; a
+    developer build is selected in code (set_library_path).  A stray variable must change nothing."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); from superslam_amd import _lib; print(_lib.LIB_PATH); "
+            "_lib.set_library_path(None); print(_lib.LIB_PATH); _lib.set_library_path('/tmp/other.so'); print(_lib.LIB_PATH)" % ROOT)
+    env = dict(os.environ, SUPERSLAM_HIP_LIBRARY="/nonexistent/evil.so", SSHIP_DEV_LIBRARY="/nonexistent/evil2.so")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout.split()
+    shipped = os.path.join(ROOT, "superslam_amd", "lib", "libsuperslam_hip.so")
+    assert out == [shipped, shipped, "/tmp/other.so"], out
+    import re
+
+    for f in os.listdir(os.path.join(ROOT, "superslam_amd")):
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "superslam_amd", f)).read()
+            names = set(re.findall(r"environ(?:\.get|\.setdefault)?[\[(]\s*[\"']([A-Z_0-9]+)", src))
+            assert not ({n for n in names if "LIBRARY" in n} - {"SSHIP_RCCL_LIBRARY"}), (f, names)

@@ -1,7 +1,8 @@
 """GPU: the A/B kernel paths of the DEVELOPER build still agree with the shipped library's single path, and the measurement probe answers.
 The shipped libsuperslam_hip.so has no kernel-selection switches (include/sship.h, "Environment"); a mode with SUPERSLAM_HIP_* switches runs on
-superslam_amd/lib/variants/dev.so (superslam_amd/build.py: DEV_SOURCES, -DSSHIP_DEV_SWITCHES=1; built by __graft_entry__.build()), loaded
-through SUPERSLAM_HIP_LIBRARY; a mode without switches runs on the shipped library.  The switches are read once per process, so every
+superslam_amd/lib/variants/dev.so (superslam_amd/build.py: DEV_SOURCES, -DSSHIP_DEV_SWITCHES=1; built by __graft_entry__.build()), which the
+worker selects EXPLICITLY (superslam_amd._lib.set_library_path through scripts/_devlib.py - the product package reads no variable for this);
+a mode without switches runs on the shipped library.  The switches are read once per process, so every
 mode runs in its own interpreter."""
 import json
 import os
@@ -19,16 +20,16 @@ DEV_LIB = os.path.join(ROOT, "superslam_amd", "lib", "variants", "dev.so")
 def _env(mode_env):
     """Process environment of one mode: switches select kernels only in the developer build."""
     env = dict(os.environ, **mode_env)
-    env.pop("SUPERSLAM_HIP_LIBRARY", None)
+    env.pop("SSHIP_DEV_LIBRARY", None)
     if mode_env:
         assert os.path.exists(DEV_LIB), "superslam_amd/lib/variants/dev.so is missing: __graft_entry__.build() produces it"
-        env["SUPERSLAM_HIP_LIBRARY"] = DEV_LIB
+        env["SSHIP_DEV_LIBRARY"] = DEV_LIB      # read by scripts/_devlib.use_dev_library() in the worker, not by the package
     return env
 
 
 _WORKER = r"""
 import sys, numpy as np
-sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/scripts'); import _devlib; _devlib.use_dev_library()
 from superslam_amd import SuperPoint, _lib
 from superslam_amd.synth import make_stereo_pair
 _lib.init(0)
@@ -129,7 +130,7 @@ def test_streaming_convpb_agrees_with_the_implicit_gemm_template(weights_dir, tm
 
 _LG_WORKER = r"""
 import sys, numpy as np, torch
-sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/scripts'); import _devlib; _devlib.use_dev_library()
 from superslam_amd import LightGlue, _lib
 _lib.init(0)
 P, K = 64, 600
@@ -208,7 +209,7 @@ def test_ffn_kernel_variants_agree(weights_dir, tmp_path, parity_report):
 
 _DENSE_WORKER = r"""
 import sys, numpy as np, torch
-sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/scripts'); import _devlib; _devlib.use_dev_library()
 from superslam_amd import SuperPoint, _lib
 from superslam_amd.synth import make_frame
 _lib.init(0)

@@ -34,6 +34,13 @@ def test_binding_compiles_against_the_reference_headers_and_passes_cpu_cases():
     print(out.stdout, out.stderr[-2000:])
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed (cpu)" in out.stdout
+    # the library's log callback is forwarded to the reference's SLOG_* (integration/reference_side/SshipLogForward.h, include/Logging.h:21-26):
+    # the three induced initialisation failures above must arrive in the logger WITH THE LIBRARY'S OWN MESSAGE, at error level, besides the
+    # adapters' own "...(HIP): ..." lines (VERDICT r05 "do this" 7: the callback existed, nothing installed it, nothing tested it)
+    fwd = [l for l in out.stderr.splitlines() if l.startswith("[error] libsuperslam_hip: {}")]
+    assert len(fwd) >= 3, out.stderr[-2000:]
+    assert any("no HIP device" in l or "superpoint.safetensors" in l for l in fwd), fwd
+    assert sum(("(HIP): {}" in l) for l in out.stderr.splitlines()) >= 3
 
 
 @pytest.mark.gpu

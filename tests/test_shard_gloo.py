@@ -115,8 +115,9 @@ def test_launcher_command_line_is_the_drivers_form():
     cmd = launcher_command("/x/bench.py", ["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29555)
     assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                    "--master-port", "29555", "/x/bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
-    free = launcher_command("/x/bench.py", [], 2)
-    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+    free = launcher_command("/x/bench.py", [], 2)     # no port given: the launcher's own store picks and holds one (no bind-and-close probe)
+    assert "--master-port" not in free and free[free.index("--standalone"):][:3] == ["--standalone", "--local-addr", "127.0.0.1"]
+    assert free[-1] == "/x/bench.py"
 
 
 def test_relaunch_only_when_no_launcher_is_around(monkeypatch):
@@ -130,7 +131,8 @@ def test_relaunch_only_when_no_launcher_is_around(monkeypatch):
     shard.relaunch_under_launcher_if_needed(8, "/x/bench.py", ["--gpus", "8", "--steps", "3"])
     assert len(calls) == 1
     f, a, e = calls[0]
-    assert a[1:7] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr"] and a[-5:] == ["/x/bench.py", "--gpus", "8", "--steps", "3"]
+    assert a[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--standalone", "--local-addr", "127.0.0.1"]
+    assert a[-5:] == ["/x/bench.py", "--gpus", "8", "--steps", "3"]
     assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     monkeypatch.setenv("RANK", "3")
     shard.relaunch_under_launcher_if_needed(8, "/x/bench.py", ["--gpus", "8"])
