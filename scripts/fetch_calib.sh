@@ -2,7 +2,7 @@
 # FETCH_SIZE calibration on k_nms_tile's access pattern (scripts/ubench/fetch_calib.hip): one rocprofv3 --pmc FETCH_SIZE pass, kernel-trace only.
 # usage (GPU box, repo root): scripts/fetch_calib.sh [out.json]
 set -e
-R=$(pwd); OUT=${1:-$R/gpurun_out/fetch_calib.json}
+R=$(pwd); OUT=${1:-$R/gpurun_out/fetch_calib.json}; case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
 [ -x scripts/ubench/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/ubench/fetch_calib scripts/ubench/fetch_calib.hip
 mkdir -p /tmp/fcal gpurun_out; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/fcal -o fc -- $R/scripts/ubench/fetch_calib > /tmp/fcal/run.log 2>&1

@@ -1686,11 +1686,14 @@ extern "C" int sship_lg_bench_stage(sship_lg* lg, int stage, int iters, float* a
   _Float16* ctx = lg->ctx.as<_Float16>();
   float* rope = lg->rope.as<float>();
   const int* lens = lg->lens_c.as<int>();
+  const bool call_splits = (size_t)2 * (pairs / 2) * lg->NP / 64 >= (size_t)2 * cu_count();  // lg_forward's two-stream condition
   auto run = [&]() -> hipError_t {
     switch (stage) {
       case 0: return launch_lg_proj_heads(w->qkv_t[0], x, d, 2, 2, rope, q, k, vt, s);
-      case 1: launch_lg_attention(q, k, vt, lens, d, false, ctx, s); return hipGetLastError();
-      case 2: launch_lg_attention(q, q, vt, lens, d, true, ctx, s); return hipGetLastError();
+      // the attention kernel the CALL launches: lg_forward runs a throughput batch as two half-batches on two streams and tells the launcher
+      // so (shared_gpu: no key split, wave-granular query units).  Rounds 2-5 timed the key-split variant here - a kernel the call never runs.
+      case 1: launch_lg_attention(q, k, vt, lens, d, false, ctx, s, call_splits); return hipGetLastError();
+      case 2: launch_lg_attention(q, q, vt, lens, d, true, ctx, s, call_splits); return hipGetLastError();
       case 3: launch_lg_ffn(w->ffn0_s[0], w->ffn3_s[0], w->ln_g_s[0], w->ln_b_s[0], ctx, x, d, &w->cqkv_t[0], true, 0, 1, rope, q, k, vt,
                             nullptr, nullptr, 0.f, nullptr, s); return hipGetLastError();
       case 4: launch_lg_ffn(w->ffn0_c[0], w->ffn3_c[0], w->ln_g_c[0], w->ln_b_c[0], ctx, x, d, &w->qkv_t[1], true, 2, 2, rope, q, k, vt,

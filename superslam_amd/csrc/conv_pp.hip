@@ -30,6 +30,9 @@
 #ifndef SSHIP_PP_EPI
 #define SSHIP_PP_EPI -1
 #endif
+#ifndef SSHIP_PP_EPI_LAST
+#define SSHIP_PP_EPI_LAST 0  // data half-step: 1 = epilogue stores AFTER the staging and the prefetch issue (A/B builds; measured slower, see data_role)
+#endif
 #ifndef SSHIP_PP_EPI_FUSED  // the same for the fused conv1a + conv1b kernel, whose data half-step also computes conv1a
 #define SSHIP_PP_EPI_FUSED 0
 #endif
@@ -44,7 +47,8 @@
 #ifndef SSHIP_PP_NBUF
 #define SSHIP_PP_NBUF 3
 #endif
-// timing / energy ablation (results are wrong): 1 = the MFMA loop reads its first fragments only and reuses them, 2 = no MFMAs (fragments still read)
+// timing / energy ablation (results are wrong): 1 = the MFMA loop reads its first fragments only and reuses them, 2 = no MFMAs (fragments still read),
+// 4 = the epilogue runs without its stores (round 6)
 #ifndef SSHIP_PP_ABL
 #define SSHIP_PP_ABL 0
 #endif
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
       int so = (row_off + cb * CT + m * 32 + g * 8) * 2;
       asm volatile("" : "+s"(so));
       typedef unsigned st4_t __attribute__((ext_vector_type(4)));
+      if constexpr ((SSHIP_PP_ABL & 4) != 0) { asm volatile("" :: "v"(r0[0]), "v"(r1[0]), "v"(r0[1]), "v"(r1[1])); return; }  // ablation: no stores
       __builtin_amdgcn_raw_buffer_store_b128(st4_t{r0[0], r1[0], r0[1], r1[1]}, ro, voff, so, 0);
     };
     if constexpr (!POOL) {
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
             const f16x_t& a = acc[m][n];
             const auto r0 = __builtin_amdgcn_permlane32_swap(relu2(a[4 * g + 0], a[4 * g + 1]), relu2(a[4 * g + 4], a[4 * g + 5]), false, false);
             const auto r1 = __builtin_amdgcn_permlane32_swap(relu2(a[4 * g + 2], a[4 * g + 3]), relu2(a[4 * g + 6], a[4 * g + 7]), false, false);
+            if constexpr ((SSHIP_PP_ABL & 4) != 0) { asm volatile("" :: "v"(r0[0]), "v"(r1[0]), "v"(r0[1]), "v"(r1[1])); continue; }  // ablation: no stores
             if (ok) *reinterpret_cast<uint4*>(pix + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
           }
       }
@@ -473,11 +479,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
   auto data_role = [&](bool do_epi, bool do_stage, bool do_prefetch, int pf_chunk, bool init_acc, bool tr) __attribute__((always_inline)) {
     if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(SSHIP_PP_PRIO);
     if (tr) t0 = __builtin_readcyclecounter();
-    if (do_epi && EPI_MFMA < 2 * MT) epilogue(EPI_MFMA, 2 * MT);
+    // Order of the three jobs.  Round 6 tested the hypothesis that the staging and the next prefetch stall behind the epilogue's 16 stores
+    // (one in-order vmcnt for loads and stores; removing the stores alone makes conv2a 33 % faster): with the epilogue LAST
+    // (-DSSHIP_PP_EPI_LAST=1) conv2a went 1 163 -> 1 183 us and conv3a 548 -> 563 us, the pooled layers did not move - refuted.  The 33 % is the
+    // power the written bytes draw (cycles per launch are within 3 % with and without stores; the clock is 45 % higher without them), not a
+    // queueing stall (profiles/r06_d_conv_store_energy.txt).  Epilogue first stays.
+    if (!SSHIP_PP_EPI_LAST && do_epi && EPI_MFMA < 2 * MT) epilogue(EPI_MFMA, 2 * MT);
     if (tr) { t1 = __builtin_readcyclecounter(); trow[0] = t1 - t0; t0 = t1; }
     if (do_stage) { if constexpr (FUSE1A) stage_conv1a(tr); else stage_in(); }
     if (tr) { t1 = __builtin_readcyclecounter(); trow[1] = t1 - t0; t0 = t1; }
     if (do_prefetch) { if constexpr (FUSE1A) prefetch_u8(); else prefetch_in(pf_chunk); }
+    if (SSHIP_PP_EPI_LAST && do_epi && EPI_MFMA < 2 * MT) epilogue(EPI_MFMA, 2 * MT);
     if (SSHIP_PP_ACC_PRELOAD && init_acc) acc_init();  // for the tile whose first MFMA half-step comes next
     if (tr) { t1 = __builtin_readcyclecounter(); trow[2] = t1 - t0; t0 = t1; }
     __syncthreads();

@@ -41,6 +41,19 @@
 #define SSHIP_PP_TRACE_BUILD 0  // role tracing (SSHIP_PP_TRACE=1 at run time), as in conv_pp.hip
 #endif
 
+// Energy ablations of conv3x3_pp128w (conv3b / conv4a / conv4b / convPa: 3.5 J = 21 % of a 64-pair call, never ablated before round 6;
+// build.py --variant pp128abl<n> -DSSHIP_PP128_ABL=<n>, scripts/dev/stage_energy.py under the power poller): 1 no MFMAs (operands still read
+// from LDS), 2 no DMA after the first item (neither the input tile chunks nor the weight ring move: no HBM / L2 -> LDS traffic),
+// 4 no epilogue (no conversion, no stores), 8 no LDS fragment reads inside the item (one set of fragments read once per item),
+// 16 the epilogue's arithmetic without its stores.  Results are wrong by design.  Measured (profiles/r06_c_conv_pp128_energy_ablation.txt):
+// MFMAs 53-60 % of a launch's joules, DMA 0-5 %, fragment reads 3-6 %, the output stores 5 % (pooled conv3b) / 33 % (conv4a, convPa).
+// The 33 % is not a stall: moving the stores behind the next half-step's DMA wait (so that nothing queues behind their acknowledgements)
+// changed nothing (254 -> 256 us); cycles per launch are within 3 % with and without stores, the CLOCK is 22 % higher without them - the
+// bytes written cost power (120-270 pJ per byte at the cap), and the layer is priced in joules.
+#ifndef SSHIP_PP128_ABL
+#define SSHIP_PP128_ABL 0
+#endif
+
 namespace sship {
 
 struct Pp128Args {
@@ -656,19 +669,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
             acc[m][n][4 * g + 0] = b4.x; acc[m][n][4 * g + 1] = b4.y; acc[m][n][4 * g + 2] = b4.z; acc[m][n][4 * g + 3] = b4.w;
           }
     }
+    if constexpr ((SSHIP_PP128_ABL & 8) != 0) {  // every register the loop reads is defined once, nothing is re-read
+      load_a(2, 2);
+#pragma unroll
+      for (int row = 4; row < 8; ++row) rows[row] = rows[row - 4];
+    }
 #pragma unroll
     for (int s_ = 0; s_ < 18; ++s_) {
       const int t = s_ / 3, ky = s_ - 3 * t;
+      if constexpr ((SSHIP_PP128_ABL & 8) == 0) {
       if (s_ + 2 < 18) load_a(s_ + 2, (s_ + 2) % 3);
       if (ky == 0) {
         load_row(t, 4); load_row(t, 5);
         if (t + 1 < 6) { load_row(t + 1, 0); load_row(t + 1, 1); }
       } else if (t + 1 < 6) load_row(t + 1, ky + 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(af[s_ % 3][m], rows[(6 * t + n + ky) & 7], acc[m][n]);
+        for (int m = 0; m < MT; ++m) {
+          if constexpr ((SSHIP_PP128_ABL & 1) != 0) asm volatile("" :: "v"(af[s_ % 3][m]), "v"(rows[(6 * t + n + ky) & 7]));
+          else acc[m][n] = mfma32(af[s_ % 3][m], rows[(6 * t + n + ky) & 7], acc[m][n]);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -699,6 +722,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
     auto store_pair = [&](_Float16* pix, int m, int g, unsigned a0, unsigned a1, unsigned b0, unsigned b1, bool ok) __attribute__((always_inline)) {
       const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
       const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      if constexpr ((SSHIP_PP128_ABL & 16) != 0) { asm volatile("" :: "v"(r0[0]), "v"(r1[0]), "v"(r0[1]), "v"(r1[1])); return; }  // everything but the store
       if (ok) *reinterpret_cast<uint4*>(pix + m * 32 + (g + hh) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     };
     if constexpr (!POOL) {
@@ -749,8 +773,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
   auto data_role = [&](int dma_chunk, int dma_half, int in_chunk, bool tr) __attribute__((always_inline)) {
     if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(SSHIP_PP_PRIO);  // ~40 instructions that decide when the DMAs start
     if (tr) t0 = __builtin_readcyclecounter();
+    if constexpr ((SSHIP_PP128_ABL & 2) != 0) {
+      if (in_chunk >= 0 && in_chunk == NCH - 1) walk_next(pw);   // the walk goes on, nothing moves
+    } else {
     if (in_chunk >= 0) dma_in(in_chunk);                    // first: the tile chunk comes from HBM half of the time, the weights from L2
     if (NCH == 4 && dma_chunk >= 0) fill_weights(dma_chunk, dma_half);
+    }
     if (SSHIP_PP_PRIO) __builtin_amdgcn_s_setprio(0);
     if (tr) { t1 = __builtin_readcyclecounter(); trow[0] = t1 - t0; t0 = t1; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -762,7 +790,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
     constexpr int chunk = decltype(chunk_c)::value;
     if (tr) t0 = __builtin_readcyclecounter();
     mfma_item(chunk_c);
-    if constexpr (chunk == NCH - 1) epilogue();
+    if constexpr (chunk == NCH - 1) {
+      if constexpr ((SSHIP_PP128_ABL & 4) != 0) {
+        walk_next(ew);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(acc[m][n]));
+      } else epilogue();
+    }
     if (tr) { t1 = __builtin_readcyclecounter(); trow[3] = t1 - t0; t0 = t1; }
     __syncthreads();
     if (tr) trow[5] = __builtin_readcyclecounter() - t0;

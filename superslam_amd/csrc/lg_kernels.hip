@@ -185,6 +185,9 @@ __device__ __forceinline__ float max_xor32(float x) {
 #ifndef SSHIP_ATTN_ABL
 #define SSHIP_ATTN_ABL 0
 #endif
+#ifndef SSHIP_ATTN_TAILSKIP
+#define SSHIP_ATTN_TAILSKIP 1  // a unit's query tiles past the sequence end are not computed (0: round 5's behaviour, computed and discarded; A/B builds)
+#endif
 __device__ __forceinline__ f16x_t mfma32_attn(h8_t a, h8_t b, f16x_t c) {
   if constexpr ((SSHIP_ATTN_ABL & 1) != 0) {
     asm volatile("" :: "v"(a), "v"(b));
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void k_lg_attention(const _Float16* __restr
     }
   };
   // wave-uniform: the unit's live query tiles (the tiles past nq keep l = 0, o = 0 and are never stored: the store loops break at nq)
-  if (QT == 1 || q0 + 32 * (QT - 1) < nq) key_loop(std::integral_constant<int, QT>{});
+  if (QT == 1 || !SSHIP_ATTN_TAILSKIP || q0 + 32 * (QT - 1) < nq) key_loop(std::integral_constant<int, QT>{});
   else key_loop(std::integral_constant<int, 1>{});
   if (SSHIP_ATTN_TRACE_BUILD && trace) tr2 = __builtin_readcyclecounter();
   if constexpr (KS == 1 && SSHIP_ATTN_REGFIN) {
