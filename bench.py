@@ -559,6 +559,7 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     ach = 2.0 * macs1 / (ms1 * 1e-3) / 1e12
     ach_iso = 2.0 * macs1 / (ms1_iso * 1e-3) / 1e12
     traffic, traffic_source = None, None
+    pmc_kernels = {}
     pmc = os.path.join(ROOT, "profiles", "pmc_conv1ab.json")
     if os.path.exists(pmc):
         try:
@@ -597,6 +598,7 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
                 raise
             if pr.returncode != 0:
                 raise RuntimeError(f"scripts/pmc_traffic.sh exited with {pr.returncode}")
+            pmc_kernels.update(json.load(open(mj)).get("kernels", {}))     # every kernel of the headline steps: the memory-bound rows below use theirs
             kj = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_conv1ab.json")))
             if kj.get("pairs_per_call") == P and kj.get("headline_launches_only"):
                 traffic = kj.get("hbm_bytes_per_launch")
@@ -722,6 +724,21 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
     # the assignment recomputes its similarity tiles on the matrix pipe instead of streaming a stored matrix: its bound is the
     # matrix pipe + VALU (it is priced in roofline_mfma as lg_assign_pass1 / pass2); the entry above is kept for its byte counts
     hbm[-1]["bound"] = "mfma+valu (by design: 11x the algorithmic bytes are re-read from L2 instead of a 92 MB fp32 matrix going through HBM four times)"
+    # counter-derived HBM bytes per launch next to the stated implementation bytes.  FETCH_SIZE x 2 holds for these kernels'
+    # access patterns too: scripts/ubench/fetch_calib.hip reads a known byte count exactly once in k_nms_tile's own per-lane pattern and the
+    # counter reports 0.5001 of it (profiles/r06_e_fetch_size_calibration.json).  Round 5's 590 MB per launch of k_nms_tile (2.1 x) was REAL:
+    # every 4 x 8-cell tile re-reads its one-cell halo ring (60 cells for 32) and neighbouring tiles ran on different XCDs.  With the XCD-aware
+    # tile order of round 6 the ring is an L2 hit: 332 MB = 1.15 x the implementation bytes, 258 -> 153 us (profiles/r06_f_nms_xcd_tile_order.txt).
+    for row, key in ((hbm[0], "k_nms_tile"), (hbm[1], "k_convpb_stream"), (hbm[2], "k_topk"), (hbm[3], "k_desc_head_sparse")):
+        hit = [v for k, v in pmc_kernels.items() if key in k]
+        if hit:
+            row["traffic"] = hit[0]["hbm_bytes_per_launch"]
+            row["traffic_source"] = "measured in this run: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the headline steps' launches (scripts/pmc_traffic.sh)"
+            row["traffic_over_algorithmic"] = round(hit[0]["hbm_bytes_per_launch"] / row["algorithmic_bytes_per_launch"], 3)
+            if "implementation_bytes_per_launch" in row:
+                row["traffic_over_implementation"] = round(hit[0]["hbm_bytes_per_launch"] / row["implementation_bytes_per_launch"], 3)
+    hbm[0]["traffic_note"] = ("a 4 x 8-cell tile loads its one-cell halo ring (6 x 10 cells = 1.83 x the cells); the XCD-aware tile order makes the ring an L2 "
+                              "hit (round 5: 590 MB per launch at the fabric); FETCH_SIZE x 2 calibrated on this access pattern (profiles/r06_e_fetch_size_calibration.json: 0.5001)")
     out["roofline_hbm"] = hbm
 
     # ---- joules per launch: every stage loops for >= --stage-energy-s seconds under the poller; energy = mean socket power x launch time ----

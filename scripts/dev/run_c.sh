@@ -1,11 +1,11 @@
 mkdir -p gpurun_out
-O=gpurun_out/energy_g.jsonl; : > $O
-for P in 2 4 8 16 64; do
-python scripts/dev/stage_energy.py --tag P$P --pairs $P --sp 1,2,3,4,5,6,8 2>/dev/null | tail -1 >> $O
-done
+V=superslam_amd/lib/variants
+PMC_EXTRA="--library $V/nms_noxcd.so" bash scripts/pmc_traffic.sh 64 gpurun_out/pmc_noxcd.json > gpurun_out/pmc_noxcd.log 2>&1
+bash scripts/pmc_traffic.sh 64 gpurun_out/pmc_xcd.json > gpurun_out/pmc_xcd.log 2>&1
 python - <<'PY'
 import json
-for l in open('gpurun_out/energy_g.jsonl'):
-    j=json.loads(l); P=int(j["tag"][1:]); print(j["tag"])
-    for r in j["rows"]: print(f'   {r["stage"]:22s} {r["launch_us"]:9.1f} us  {r["avg_W"]:7.1f} W  {r["sclk_MHz"]:6.0f} MHz  {r["joules_per_launch"]:.4f} J   per image: {r["launch_us"]/(2*P):8.2f} us {r["joules_per_launch"]/(2*P)*1e3:8.3f} mJ')
+for t in ("noxcd","xcd"):
+    j=json.load(open(f"gpurun_out/pmc_{t}.json"))
+    for k,v in j["kernels"].items():
+        if "nms" in k or "convpb" in k or "topk" in k or "desc_head" in k: print(t, k[:60], v["launches"], "fetch x2 MB", round(2*v["FETCH_SIZE_KB_mean"]/1e3,1), "write MB", round(v["WRITE_SIZE_KB_mean"]/1e3,1), "total MB", round(v["hbm_bytes_per_launch"]/1e6,1))
 PY

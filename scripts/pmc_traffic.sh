@@ -3,15 +3,15 @@
 # WRITE_SIZE in SEPARATE --pmc passes (TCC slots), kernel-trace only; FETCH_SIZE is doubled on gfx950 for wide coalesced
 # reads.  The profiled command is `bench.py --headline-only`: EVERY launch in the trace is a headline launch of <pairs>
 # pairs (round 1 averaged the 2-image latency-loop launches into the mean - VERDICT r01 "What's weak" 6).
-# usage (on the GPU box, from the repo root): scripts/pmc_traffic.sh <pairs> [out.json]
+# usage (on the GPU box, from the repo root): [PMC_EXTRA="--library lib/variants/x.so"] scripts/pmc_traffic.sh <pairs> [out.json]
 set -e
 P=${1:-64}
 R=$(pwd)
-OUT=${2:-$R/gpurun_out/pmc_traffic.json}
+OUT=${2:-$R/gpurun_out/pmc_traffic.json}; case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
 mkdir -p /tmp/pmc_t gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_t -o t_$c -- python $R/bench.py --headline-only --steps 2 --warmup 1 --chunks 2 --pairs $P > /tmp/pmc_t/run_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_t -o t_$c -- python $R/bench.py --headline-only --no-power --steps 2 --warmup 1 --chunks 2 --pairs $P $PMC_EXTRA > /tmp/pmc_t/run_$c.log 2>&1
 done
 python - "$R" "$P" "$OUT" <<'PY'
 import hashlib, json, sqlite3, sys, time

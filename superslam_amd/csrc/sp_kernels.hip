@@ -103,6 +103,9 @@ __device__ __forceinline__ void window9x4(const float (&v)[12], float (&o)[4]) {
 //     the tile's candidates are parked in a small LDS list and written out one tile later, when the ticket has long
 //     returned (tiles with more than NMS_PEND candidates - constant plateaus - take the synchronous path).
 constexpr int NMS_PEND = 256;
+#ifndef SSHIP_NMS_XCD
+#define SSHIP_NMS_XCD 1  // XCD-aware tile order (0: tile = id + k * grid, rounds 1-5; A/B builds)
+#endif
 
 template <int LOADER, int RT>
 __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
@@ -150,9 +153,21 @@ __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
         if (base + i < a.cap) a.cand[(size_t)pend_b * a.cap + base + i] = s_pend[i];
     }
   };
-  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  // XCD-aware tile order (round 6).  A tile re-reads its one-cell halo ring: 60 cells for 32.  The dispatcher deals consecutive workgroup ids
+  // round-robin over the 8 XCDs, so with `tile = id + k * grid` the workgroups that hold NEIGHBOURING tiles at the same moment sat on eight
+  // different XCDs, each with its own L2, and every ring came over the fabric: 590 MB per 128-image launch against 288 MB of logits
+  // (FETCH_SIZE calibrated on this access pattern: profiles/r06_e_fetch_size_calibration.json).  Now XCD x owns the CONTIGUOUS tile range
+  // [x per, (x + 1) per) and its workgroups walk it together (workgroup q of the XCD takes tiles q, q + Q, ...): at any moment an XCD holds
+  // ~160 consecutive tiles = seven tile rows, so a ring cell is fetched once by the XCD's L2 and hit by the neighbours.  Placement is a
+  // speed assumption only: any mapping computes the same candidates (their order in the per-image list is arbitrary either way; k_topk sorts).
+  const bool xcd_map = SSHIP_NMS_XCD && (gridDim.x & 7) == 0 && gridDim.x >= 8;
+  const int xq = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, xQ = xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int per = xcd_map ? (ntiles + 7) >> 3 : ntiles, xbase = xcd_map ? (int)(blockIdx.x & 7) * per : 0;
+  const int t_end = min(per, ntiles - xbase);  // tiles of this workgroup's range (may be <= 0 for the last XCD of a small launch)
+  if (xq < t_end) fetch(xbase + xq);
 #pragma unroll 1
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tl = xq; tl < t_end; tl += xQ) {
+    const int tile = xbase + tl;
     int t = tile;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(256) void k_nms_tile(NmsArgs a) {
           }
         }
       }
-      if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // lands while this tile goes through its LDS phases
+      if (tl + xQ < t_end) fetch(tile + xQ);  // lands while this tile goes through its LDS phases
     } else {
       for (int i = tid; i < NLH * NLW; i += 256) {
         const int ly = i / NLW, lx = i % NLW;

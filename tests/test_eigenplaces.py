@@ -269,6 +269,75 @@ def test_other_engine_sizes_against_the_oracle(ep_weights, in_w, in_h):
 
 
 @pytest.mark.gpu
+def test_descriptor_on_a_side_stream_while_the_tracker_runs(ep_weights, weights_dir, parity_report):
+    """The deployment of SURVEY 8(f) row 4: the loop-closure thread asks for a global descriptor while the tracking thread's front-end call
+    (persistent one-workgroup-per-CU convolution kernels) owns the GPU.  Round 5's aggregation tail spun on a grid barrier that assumed its 8
+    workgroups start together - exactly what a GPU full of persistent workgroups does not promise; the tail is two stream-ordered launches now.
+    Here: descriptors computed on a side stream DURING back-to-back 16-pair front-end calls are bit-identical to the quiet ones, every call
+    completes, and a descriptor never takes longer than its quiet time plus two front-end calls (it queues behind at most the kernels already
+    resident, never behind a spin)."""
+    import ctypes as C
+
+    from superslam_amd import FrontEndBatch, LightGlue, SuperPoint, _lib
+    from superslam_amd.synth import make_stereo_pair
+
+    sd, path = ep_weights
+    _lib.init(0)
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.sship_ep_create(path.encode(), 512, 512, C.byref(h)))
+    img = make_frame(376, 1241, 21)
+    dimg = torch.from_numpy(img).cuda()
+    quiet = torch.zeros(512, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        _lib.check(L.sship_ep_infer_u8_device(h, dimg.data_ptr(), 376, 1241, 1241, 1, quiet.data_ptr(), side.cuda_stream))
+    side.synchronize()
+    e0.record(side)
+    for _ in range(10):
+        _lib.check(L.sship_ep_infer_u8_device(h, dimg.data_ptr(), 376, 1241, 1241, 1, quiet.data_ptr(), side.cuda_stream))
+    e1.record(side); side.synchronize()
+    quiet_ms = e0.elapsed_time(e1) / 10
+    # the tracker: 16 stereo pairs per call, as many calls as it takes to cover the descriptors
+    P, Hh, Ww = 16, 376, 1376
+    sp = SuperPoint(weights_dir["sp_path"], 600, 0.005, 4, max_batch=2 * P); assert sp.initialize(), sp.last_error
+    lg = LightGlue(weights_dir["lg_path"], Ww, Hh, max_keypoints=600, max_pairs=P); assert lg.initialize(), lg.last_error
+    fe = FrontEndBatch(sp, lg, P, Hh, Ww)
+    l, r = make_stereo_pair(Hh, Ww, 5)
+    imgs = torch.from_numpy(np.stack([l, r] * P)).cuda()
+    main = torch.cuda.current_stream()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fe.run(imgs, main.cuda_stream); torch.cuda.synchronize()
+    f0.record(main)
+    for _ in range(4):
+        fe.run(imgs, main.cuda_stream)
+    f1.record(main); torch.cuda.synchronize()
+    fe_ms = f0.elapsed_time(f1) / 4
+    m_ref = fe.matches0.clone()
+    outs = [torch.zeros(512, dtype=torch.float32, device="cuda") for _ in range(8)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+    for i in range(8):                       # interleave on the host: a front-end call is queued, then a descriptor on the other stream
+        fe.run(imgs, main.cuda_stream)
+        fe.run(imgs, main.cuda_stream)
+        evs[i][0].record(side)
+        _lib.check(L.sship_ep_infer_u8_device(h, dimg.data_ptr(), 376, 1241, 1241, 1, outs[i].data_ptr(), side.cuda_stream))
+        evs[i][1].record(side)
+    torch.cuda.synchronize()
+    busy_ms = [a.elapsed_time(b) for a, b in evs]
+    for o in outs:
+        assert torch.equal(o, quiet)
+    assert torch.equal(fe.matches0, m_ref)
+    print(f"EigenPlaces beside a running tracker: quiet {quiet_ms:.3f} ms per descriptor, beside {P}-pair front-end calls of {fe_ms:.2f} ms: "
+          f"{min(busy_ms):.3f} .. {max(busy_ms):.3f} ms, bit-identical")
+    assert max(busy_ms) <= quiet_ms + 2 * fe_ms + 1.0, (busy_ms, quiet_ms, fe_ms)
+    parity_report["eigenplaces_beside_tracker"] = {"quiet_ms": round(quiet_ms, 4), "busy_ms_max": round(max(busy_ms), 4), "frontend_call_ms": round(fe_ms, 3),
+                                                   "bit_identical": True}
+    sp.close(); lg.close()
+    L.sship_ep_destroy(h)
+
+
+@pytest.mark.gpu
 def test_global_descriptor_vs_oracle(ep_weights, parity_report):
     from superslam_amd import EigenPlaces
 
