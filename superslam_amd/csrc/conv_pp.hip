@@ -30,6 +30,9 @@
 #ifndef SSHIP_PP_EPI
 #define SSHIP_PP_EPI -1
 #endif
+#ifndef SSHIP_PP_COLMAJOR
+#define SSHIP_PP_COLMAJOR 1  // tile walk down the columns (0: raster order, rounds 1-5; A/B builds)
+#endif
 #ifndef SSHIP_PP_EPI_LAST
 #define SSHIP_PP_EPI_LAST 0  // data half-step: 1 = epilogue stores AFTER the staging and the prefetch issue (A/B builds; measured slower, see data_role)
 #endif
@@ -126,18 +129,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) boff[kx][ks] = (j + kx) * 64 + (((2 * ks + hh) ^ (((j + kx) >> 1) & 7)) << 3);
 
+  // Tile order inside a workgroup's contiguous range.  SSHIP_PP_COLMAJOR = 1 (round 6): down the tile COLUMNS (ty fastest).  The two groups of
+  // a workgroup take alternate tiles, so with this order the tiles in flight are vertical neighbours and the two halo rows they share (2 of
+  // 10 input rows) are L2 hits; the 2 of 34 halo columns shared with the next tile column come around tiles_y tiles later.  With the raster
+  // order of rounds 1-5 (tx fastest) it was the other way round: the halo rows were re-fetched tiles_x tiles later, long after the XCD's
+  // 4-MiB L2 had turned over - conv2a / conv2b read 1.2-1.25 x their input (profiles/r05_final_pmc_traffic.json).  Measured
+  // (profiles/r06_g_conv_tile_walk.txt): conv2b's fetch 2 577 -> 2 197 MB per launch (1.04 x its input), conv2a + conv3a -14 %, joules -0.8 % / -1.1 %.
+  // NOT for the fused conv1a + conv1b kernel: its input is the u8 image, 34 bytes of a 128-byte line per tile row - in column order the line's
+  // other tiles come 47 tiles later and the line is fetched four times (102 -> 386 MB, +0.4 % joules); it keeps the raster order.
   auto walk_init = [&](int t) __attribute__((always_inline)) {
     PpWalk w;
-    w.tx = t % tiles_x;
-    const int r = t / tiles_x;
-    w.ty = r % tiles_y; w.b = r / tiles_y;
+    if constexpr (SSHIP_PP_COLMAJOR != 0 && !FUSE1A) {
+      w.ty = t % tiles_y;
+      const int r = t / tiles_y;
+      w.tx = r % tiles_x; w.b = r / tiles_x;
+    } else {
+      w.tx = t % tiles_x;
+      const int r = t / tiles_x;
+      w.ty = r % tiles_y; w.b = r / tiles_y;
+    }
     return w;
   };
-  auto walk_next = [&](PpWalk& w) __attribute__((always_inline)) {  // two tiles further along the (b, ty, tx) raster
-    w.tx += 2;
-    while (w.tx >= tiles_x) {
-      w.tx -= tiles_x;
-      if (++w.ty == tiles_y) { w.ty = 0; ++w.b; }
+  auto walk_next = [&](PpWalk& w) __attribute__((always_inline)) {  // two tiles further along the walk
+    if constexpr (SSHIP_PP_COLMAJOR != 0 && !FUSE1A) {
+      w.ty += 2;
+      while (w.ty >= tiles_y) {
+        w.ty -= tiles_y;
+        if (++w.tx == tiles_x) { w.tx = 0; ++w.b; }
+      }
+    } else {
+      w.tx += 2;
+      while (w.tx >= tiles_x) {
+        w.tx -= tiles_x;
+        if (++w.ty == tiles_y) { w.ty = 0; ++w.b; }
+      }
     }
   };
   PpWalk pw = walk_init(t_begin + grp), sw = pw, ew = pw;  // tile of the next prefetch / staging / epilogue

@@ -53,6 +53,9 @@
 #ifndef SSHIP_PP128_ABL
 #define SSHIP_PP128_ABL 0
 #endif
+#ifndef SSHIP_PP128_COLMAJOR
+#define SSHIP_PP128_COLMAJOR 0  // conv3x3_pp128w: 1 = tile walk down the columns (A/B builds; measured: fetch -1 %, joules +-0 - the 16-row tiles share 2 of 18 rows)
+#endif
 
 namespace sship {
 
@@ -503,18 +506,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp128w(Pp128Args p) {
 #pragma unroll
     for (int ksl = 0; ksl < 2; ++ksl) boff[kx][ksl] = (j + kx) * 32 + (((2 * ksl + hh) ^ (((j + kx) >> 2) & 3)) << 3);
 
+  // SSHIP_PP128_COLMAJOR = 1 (round 6 experiment, off): the walk runs down the tile columns (ty fastest) as in conv_pp.hip.  Measured: no gain here
+  // (fetch 1 270 -> 1 256 MB on conv3b, joules unchanged): profiles/r06_g_conv_tile_walk.txt.
   auto walk_init = [&](int t) __attribute__((always_inline)) {
     TileWalk w;
-    w.tx = t % tiles_xv;
-    const int r = t / tiles_xv;
-    w.ty = r % tiles_y; w.b = r / tiles_y;
+    if constexpr (SSHIP_PP128_COLMAJOR != 0) {
+      w.ty = t % tiles_y;
+      const int r = t / tiles_y;
+      w.tx = r % tiles_xv; w.b = r / tiles_xv;
+    } else {
+      w.tx = t % tiles_xv;
+      const int r = t / tiles_xv;
+      w.ty = r % tiles_y; w.b = r / tiles_y;
+    }
     return w;
   };
   auto walk_next = [&](TileWalk& w) __attribute__((always_inline)) {
-    w.tx += 2;
-    while (w.tx >= tiles_xv) {
-      w.tx -= tiles_xv;
-      if (++w.ty == tiles_y) { w.ty = 0; ++w.b; }
+    if constexpr (SSHIP_PP128_COLMAJOR != 0) {
+      w.ty += 2;
+      while (w.ty >= tiles_y) {
+        w.ty -= tiles_y;
+        if (++w.tx == tiles_xv) { w.tx = 0; ++w.b; }
+      }
+    } else {
+      w.tx += 2;
+      while (w.tx >= tiles_xv) {
+        w.tx -= tiles_xv;
+        if (++w.ty == tiles_y) { w.ty = 0; ++w.b; }
+      }
     }
   };
   // virtual (tx, b) of the walk -> image, tile column, and whether this is a shared edge tile
