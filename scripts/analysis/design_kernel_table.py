@@ -12,15 +12,15 @@ P = b["config"]["pairs_per_call"]
 ROWS = [  # (bench key, table name, work per pair, one-line design)
     ("conv1a+conv1b+pool", "`conv3x3_pp<64,64,pool,fuse1a>` conv1a + conv1b + pool — **dominant** (`conv_pp.hip`)", "77.5 GFLOP (36 %); 1.03 MB u8 in, 33.1 MB out",
      "persistent workgroup per CU, conv1b weights resident in LDS, two 4-wave role groups ping-pong MFMA half-steps against staging / epilogue; conv1a evaluated with MFMAs (K = 9 → 16) straight from u8 dwords into the LDS tile: the full-resolution 64-channel map never exists in HBM"),
-    ("conv2a", "`conv3x3_pp<64,64>` conv2a (`conv_pp.hip`)", "9.5 GFLOP; 33.1 MB in + 33.1 MB out (288 FLOP/B: **at the ridge**)", "same kernel; staging addresses affine (one VGPR offset + scalar row offsets), out-of-image halo by the buffer range check"),
-    ("conv2b+pool", "conv2b + pool (`conv_pp.hip`)", "9.5 GFLOP; 33.1 MB in + 8.3 MB out", "same; pool on raw accumulators (`v_max3` + DPP)"),
+    ("conv2a", "`conv3x3_pp<64,64>` conv2a (`conv_pp.hip`)", "9.5 GFLOP; 33.1 MB in + 33.1 MB out (288 FLOP/B: **at the ridge**)", "same kernel; staging addresses affine (one VGPR offset + scalar row offsets), out-of-image halo by the buffer range check; round 6: tiles walked down the columns - the halo rows two tiles share are L2 hits (fetch −14 %)"),
+    ("conv2b+pool", "conv2b + pool (`conv_pp.hip`)", "9.5 GFLOP; 33.1 MB in + 8.3 MB out", "same; pool on raw accumulators (`v_max3` + DPP); column walk: fetch 2 577 → 2 197 MB per launch (1.04 × the input)"),
     ("conv3a", "conv3a 64 → 128 (`conv_pp.hip`)", "4.8 GFLOP; 8.3 + 16.6 MB", "same kernel, two cout tiles"),
     ("conv3b+pool", "`conv3x3_pp128w<pool>` conv3b (`conv_pp128.hip`)", "9.5 GFLOP; 16.6 + 4.1 MB", "16×32-pixel tiles, input chunk global → LDS by `buffer_load … lds` (swizzle on the source address, zeros from the range check), weight ring by LDS-DMA, 0.5 `ds_read_b128` per MFMA (tap rows share row fragments)"),
     ("conv4a", "conv4a (`conv_pp128.hip`)", "2.4 GFLOP; 4.1 + 4.1 MB", "same; the 12-column right-edge strips of two images share one tile (33 tiles per image pair instead of 36)"),
     ("conv4b", "conv4b", "2.4 GFLOP; 4.1 + 4.1 MB", "same"),
     ("convPa", "convPa 128 → 256", "4.8 GFLOP; 4.1 + 8.3 MB", "same, four cout tiles"),
     ("lg_wqkv0_proj", "`k_lg_ffn4<3,true,PROJ>` first Wqkv (`lg_kernels.hip`)", "0.47 GFLOP", "the FFN kernel's projection stage on its own (rotary epilogue, Q/K/V^T written in fragment order)"),
-    ("lg_self_attention", "`k_lg_attention<2,1,3>` ×9 self (`lg_kernels.hip`)", "9 × 0.74 GFLOP", "swapped QKᵀ (lane owns a query), reference exponent riding in the QKᵀ MFMA chain, interleaved chains of two query tiles, K/V^T fragments prefetched a tile ahead, XCD-aware workgroup mapping, register finalisation; round 5: context rows leave as whole 128-B lines through a wave-private LDS patch"),
+    ("lg_self_attention", "`k_lg_attention<2,1,3>` ×9 self (`lg_kernels.hip`)", "9 × 0.74 GFLOP", "swapped QKᵀ (lane owns a query), reference exponent riding in the QKᵀ MFMA chain, interleaved chains of two query tiles, K/V^T fragments prefetched a tile ahead, XCD-aware workgroup mapping, register finalisation; round 5: context rows leave as whole 128-B lines through a wave-private LDS patch; round 6: a unit's query tile past the sequence end is not computed (the row is now the kernel the CALL launches - rounds 2-5 timed the key-split variant here)"),
     ("lg_cross_attention", "… ×9 cross", "9 × 0.74 GFLOP", "same launch shape; sequence s attends to s^1"),
     ("lg_self_ffn+to_qk|to_v", "`k_lg_ffn4<2,…>` ×9 SelfBlock FFN + CrossBlock projection", "9 × 1.42 GFLOP", "4 waves per workgroup, 2 workgroups per CU, 64-token tile: ffn.0 (out_proj folded) → LayerNorm → GELU (degree-4 minimax σ form) → ffn.3 + residual → next projection on the tile already in LDS; weights stream from L2 through a register ring; round 5: the new x rows leave from the LDS tile as whole 512-B rows"),
     ("lg_cross_ffn+wqkv", "`k_lg_ffn4<3,…>` ×8 CrossBlock FFN + next Wqkv", "8 × 1.51 GFLOP", "same"),
@@ -33,15 +33,18 @@ for key, name, work, design in ROWS:
     bound = e.get("bound", "mfma + VALU phases" if key.startswith("lg_") else "mfma")
     extra = f", {e['achieved_gb_per_s'] / 1000:.2f} TB/s = {e['frac_of_hbm_peak']:.2f} of HBM" if "achieved_gb_per_s" in e else ""
     per = "" if not key.startswith("lg_") else " per launch"
-    print(f"| {name} | {bound} | {work} | {e['launch_ms'] * 1e3:.0f} µs{per}, {e['achieved']:.0f} TFLOP/s = **{e['frac']:.3f}**{extra} | {design} |")
+    joule = f", **{e['joules_per_launch']:.3f} J** at {e['avg_W']:.0f} W / {e['sclk_MHz']:.0f} MHz" if e.get("joules_per_launch") else ""
+    print(f"| {name} | {bound} | {work} | {e['launch_ms'] * 1e3:.0f} µs{per}, {e['achieved']:.0f} TFLOP/s = **{e['frac']:.3f}**{extra}{joule} | {design} |")
 HB = [("k_convpb_stream", "`k_convpb_stream` convPb 1×1 256 → 65 (`sp_convs.hip`)", "streaming kernel, nothing staged through LDS: `v_mfma_f32_16x16x32_f16` with pixels as N, weights in registers, fp32 logits in 68-float rows"),
-      ("k_nms_tile", "`k_nms_tile` softmax + depth-to-space + 9×9 NMS + threshold + compaction (`sp_kernels.hip`)", "persistent over tiles, separable max in LDS, candidates compacted with one LDS atomic per wave"),
+      ("k_nms_tile", "`k_nms_tile` softmax + depth-to-space + 9×9 NMS + threshold + compaction (`sp_kernels.hip`)", "persistent over tiles, separable max in LDS, candidates compacted with one LDS atomic per wave; round 6: XCD-aware tile order - neighbouring tiles run on ONE XCD, the one-cell halo ring is an L2 hit (590 → 332 MB per launch, 258 → 153 µs isolated)"),
       ("k_topk", "`k_topk` (one workgroup per image)", "register-cached MSB radix select with early exit + barrier-free rank sort; writes keypoints and cells"),
       ("k_desc_head_sparse", "`k_desc_head_sparse` convDa + convDb + normalise ×2 at the keypoints (`sp_convs.hip`)", "3×3×128 patches gathered as nine 256-B rows; same k order as the dense kernels → bit-identical rows")]
 for key, name, design in HB:
     e = hb[key]
-    print(f"| {name} | HBM / latency | {e['algorithmic_bytes_per_launch'] / (2 * P) / 1e6:.2f} MB per image | {e['launch_ms'] * 1e3:.0f} µs, {e['achieved'] / 1000:.2f} TB/s = {e['frac']:.2f} of HBM | {design} |")
+    joule = f", {e['joules_per_launch']:.3f} J at {e['avg_W']:.0f} W" if e.get("joules_per_launch") else ""
+    traffic = f"; counters: {e['traffic'] / 1e6:.0f} MB per launch = {e['traffic_over_algorithmic']:.2f} x algorithmic" if e.get("traffic") else ""
+    print(f"| {name} | HBM / latency | {e['algorithmic_bytes_per_launch'] / (2 * P) / 1e6:.2f} MB per image | {e['launch_ms'] * 1e3:.0f} µs, {e['achieved'] / 1000:.2f} TB/s = {e['frac']:.2f} of HBM{joule}{traffic} | {design} |")
 lg = b["lightglue_mfma"]
 print(f"| LightGlue call (`api.hip: lg_forward`) | — | 38.85 GFLOP | {lg['ms_per_call']:.2f} ms per 64 pairs = **{lg['frac']:.3f}** of the MFMA peak | the nine layers run as two half-batches on two streams (fork after `k_lg_prep`, join before the assignment): the other stream's kernels fill the partly filled last workgroup round of every launch |")
 ep = b["eigenplaces"]
-print(f"| EigenPlaces (`ep_kernels.hip`, off the per-frame path) | launch latency at batch 1 | 19 GFLOP per descriptor | {ep['ms_per_descriptor']:.3f} ms synchronous, {ep['ms_per_descriptor_device_resident']:.3f} ms device-resident | u8 upload, device fixed-point resize + normalise, BN folded, implicit-GEMM template with split-K (fp32 partials + one finish kernel) where a layer would leave CUs idle, 8-workgroup GeM / FC tail with a grid barrier |")
+print(f"| EigenPlaces (`ep_kernels.hip`, off the per-frame path) | launch latency at batch 1 | 19 GFLOP per descriptor | {ep['ms_per_descriptor']:.3f} ms synchronous, {ep['ms_per_descriptor_device_resident']:.3f} ms device-resident | u8 upload, device fixed-point resize + normalise, BN folded, implicit-GEMM template with split-K (fp32 partials + one finish kernel) where a layer would leave CUs idle, GeM / FC tail as two stream-ordered 8-workgroup launches (round 6: no spin barrier) |")

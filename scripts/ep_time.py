@@ -13,6 +13,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _devlib  # noqa: E402
+
+_devlib.use_dev_library()   # A/B only: SSHIP_DEV_LIBRARY names the developer build (SUPERSLAM_HIP_EP_STEM=gemm); unset = the shipped library
 from superslam_amd import _lib  # noqa: E402
 from superslam_amd import eigenplaces as P  # noqa: E402
 from superslam_amd.synth import make_frame  # noqa: E402

@@ -1807,7 +1807,8 @@ struct sship_ep {
   float* fc_wt = nullptr;   // [in 512][out 512] fp32 (transposed)
   float* fc_b = nullptr;
   float gem_p = 3.f;
-  DevBuf d_in, patches, act[4], d_out;
+  DevBuf d_in, patches, act[4], d_out;   // patches: the im2col matrix of the GEMM stem (developer build's A/B path only)
+  DevBuf stem_frag, stem_bias;           // fused stem (round 6): [2][11][64][8] fp16 A fragments, fp32 bias [64]
   PinBuf h_out;
   DevBuf d_ws, d_tail;      // split-K partial sums; the tail's [512] pre-normalisation outputs + its arrival counter
   DevBuf d_img;             // u8 entry points: the uploaded image
@@ -1853,6 +1854,25 @@ extern "C" int sship_ep_create(const char* weights_path, int input_w, int input_
       bf[co] = be->data[co] - mu->data[co] * sc;
       for (int i = 0; i < cin * kk; ++i) wf[(size_t)co * (flat ? cin_pad : cin * kk) + i] = w->data[(size_t)co * cin * kk + i] * sc;
     }
+    if (flat) {
+      // the fused stem kernel's A fragments (ep_kernels.hip: k_ep_stem_pool): fragment (m, s), lane (row, kg) = W'[32 m + row][idx = 2 s + kg][kx 0..7],
+      // idx = c * 7 + ky; idx = 21 and kx = 7 are zero padding of K
+      std::vector<_Float16> fr((size_t)2 * 11 * 64 * 8);
+      for (int m = 0; m < 2; ++m)
+        for (int st = 0; st < 11; ++st)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const int row = lane & 31, idx = 2 * st + (lane >> 5);
+              float v = 0.f;
+              if (idx < cin * ks && e < ks) v = wf[(size_t)(32 * m + row) * cin_pad + (idx / ks) * kk + (idx % ks) * ks + e];
+              fr[((size_t)(m * 11 + st) * 64 + lane) * 8 + e] = (_Float16)v;
+            }
+      SSHIP_HIP_CHECK(ep->stem_frag.ensure(fr.size() * sizeof(_Float16)));
+      SSHIP_HIP_CHECK(hipMemcpy(ep->stem_frag.p, fr.data(), fr.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      SSHIP_HIP_CHECK(ep->stem_bias.ensure(bf.size() * sizeof(float)));
+      SSHIP_HIP_CHECK(hipMemcpy(ep->stem_bias.p, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+      if (!SSHIP_DEV_SWITCHES) return SSHIP_OK;   // the GEMM form of the stem exists in the developer build only (A/B: SUPERSLAM_HIP_EP_STEM=gemm)
+    }
     return upload_conv(wf.data(), bf.data(), cout, flat ? cin_pad : cin, flat ? 1 : ks, 64, dst);
   };
   if (int rc = folded("backbone.0", "backbone.1", 64, 3, 7, 192, ep->stem)) return rc;
@@ -1886,7 +1906,7 @@ extern "C" int sship_ep_create(const char* weights_path, int input_w, int input_
   }
   const int Ho = (input_h - 1) / 2 + 1, Wo = (input_w - 1) / 2 + 1;
   SSHIP_HIP_CHECK(ep->d_in.ensure((size_t)3 * input_h * input_w * 4));
-  SSHIP_HIP_CHECK(ep->patches.ensure((size_t)Ho * Wo * 192 * 2));
+  if (SSHIP_DEV_SWITCHES) SSHIP_HIP_CHECK(ep->patches.ensure((size_t)Ho * Wo * 192 * 2));
   for (auto& a : ep->act) SSHIP_HIP_CHECK(a.ensure((size_t)Ho * Wo * 64 * 2));
   SSHIP_HIP_CHECK(ep->d_out.ensure(512 * 4));
   SSHIP_HIP_CHECK(ep->h_out.ensure(512 * 4));
@@ -1909,11 +1929,17 @@ extern "C" int sship_ep_preprocess(const uint8_t* img, int h, int w, int stride,
 static int ep_network(sship_ep* ep, float* desc_dev, hipStream_t s) {
   const int H = ep->in_h, W = ep->in_w;
   int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
-  launch_ep_im2col(ep->d_in.as<float>(), H, W, h, w, ep->patches.as<_Float16>(), s);
   _Float16* a[4] = {ep->act[0].as<_Float16>(), ep->act[1].as<_Float16>(), ep->act[2].as<_Float16>(), ep->act[3].as<_Float16>()};
-  SSHIP_HIP_CHECK(ep_conv(ep->stem, ep->patches.as<_Float16>(), a[0], nullptr, h, w, true, false, s));
   const int hp = (h - 1) / 2 + 1, wp = (w - 1) / 2 + 1;  // MaxPool2d(3, 2, 1)
-  launch_ep_maxpool(a[0], h, w, hp, wp, a[1], s);
+#if SSHIP_DEV_SWITCHES  // A/B: the stem of rounds 3-5 (im2col -> 1x1 GEMM -> max-pool, three launches)
+  static const bool stem_gemm = [] { const char* e = dev_env("SUPERSLAM_HIP_EP_STEM"); return e && std::string(e) == "gemm"; }();
+  if (stem_gemm) {
+    launch_ep_im2col(ep->d_in.as<float>(), H, W, h, w, ep->patches.as<_Float16>(), s);
+    SSHIP_HIP_CHECK(ep_conv(ep->stem, ep->patches.as<_Float16>(), a[0], nullptr, h, w, true, false, s));
+    launch_ep_maxpool(a[0], h, w, hp, wp, a[1], s);
+  } else
+#endif
+  launch_ep_stem_pool(ep->d_in.as<float>(), H, W, h, w, hp, wp, ep->stem_frag.as<_Float16>(), ep->stem_bias.as<float>(), a[1], s);
   h = hp; w = wp;
   int cur = 1;  // index of the buffer holding the block input
   for (const auto& blk : ep->blocks) {

@@ -254,6 +254,109 @@ void launch_ep_maxpool(const _Float16* in, int H, int W, int Ho, int Wo, _Float1
   hipLaunchKernelGGL(k_ep_maxpool, dim3((n + 255) / 256), dim3(256), 0, s, in, H, W, Ho, Wo, out);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused stem (round 6): conv 7x7 / stride 2 / pad 3, 3 -> 64 (BatchNorm folded) + ReLU + MaxPool2d(3, 2, 1) in ONE kernel.
+// Rounds 3-5 ran it as im2col (25 MB of fp16 patch rows written and read back: 17.9 us) -> 1x1 GEMM over 192-wide rows (11.8 us) -> max-pool
+// (5.6 us; the 8 MB stem map written and read back): 35 us of a 250-us descriptor for 1.2 of its 19 GFLOP.
+// Here a workgroup owns an 8 x 8 tile of the POOLED map: it needs the 17 x 17 stem pixels around it and those need a 39 x 39 x 3 input patch,
+// which is staged into LDS as fp16 once.  The GEMM runs on the matrix cores with the patch as the B operand built ON THE FLY: k is ordered
+// (c, ky, kx padded to 8) so that a lane's 8-element k-slice is 8 CONSECUTIVE input pixels of one patch row - four ds_read_b32 from a 4-byte
+// aligned address (the pixel's window starts at the even column 2 sx) - instead of a row of a materialised im2col matrix; kx = 7 carries a zero
+// weight.  K = 21 rows x 8 = 168 -> 11 k-steps of 16; the 22 weight fragments (2 M-tiles x 11) live in 88 VGPRs for the whole kernel.
+// Stem pixels go to LDS as fp16 (pixels outside the stem map as 0: every pooling window holds at least one real pixel and ReLU outputs are >= 0,
+// so 0 is as good as the -inf padding of MaxPool2d), the pooled 8 x 8 x 64 tile leaves as whole 128-byte rows.  Neither the patch matrix nor
+// the stem map exists in HBM.
+// wfrag: [m 2][s 11][lane 64][8] fp16, lane (row = lane & 31, kg = lane >> 5) of fragment (m, s) = W[32 m + row][idx = 2 s + kg][kx = e]
+// (idx = c * 7 + ky; idx = 21 and kx = 7 are zero).  Same rounding points as the GEMM path (fp16 operands, fp32 accumulate, bias, ReLU, fp16).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kStemPT = 8;                       // pooled tile edge
+constexpr int kStemST = 2 * kStemPT + 1;         // 17 stem pixels per edge
+constexpr int kStemIT = 2 * kStemST + 5;         // 39 input pixels per edge
+constexpr int kStemIW = 40;                      // patch row stride (halfs): column 39 is the zero-weight tap of the last window
+constexpr int kStemLd = 72;                      // stem pixel stride in LDS (halfs): 64 channels + 8 (bank spread for the 16-byte pooling reads)
+constexpr int kStemNpx = kStemST * kStemST;      // 289 stem pixels = 10 N-tiles of 32 (320 slots)
+__global__ __launch_bounds__(256) void k_ep_stem_pool(const float* __restrict__ x, int H, int W, int Ho, int Wo, int Hp, int Wp,
+                                                      const _Float16* __restrict__ wfrag, const float* __restrict__ bias,
+                                                      _Float16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) _Float16 s_in[3 * kStemIT * kStemIW];
+  __shared__ __attribute__((aligned(16))) _Float16 s_st[320 * kStemLd];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 31, kg = lane >> 5;
+  const int tiles_x = (Wp + kStemPT - 1) / kStemPT;
+  const int py0 = (blockIdx.x / tiles_x) * kStemPT, px0 = (blockIdx.x % tiles_x) * kStemPT;
+  const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;     // first stem pixel of the tile (may be -1: pooling padding)
+  const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;     // first input pixel of the patch
+  // weights: 22 fragments, once
+  h8_t wf[2][11];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int s = 0; s < 11; ++s) wf[m][s] = *reinterpret_cast<const h8_t*>(wfrag + ((size_t)(m * 11 + s) * 64 + lane) * 8);
+  // input patch -> LDS (fp16, zeros outside the image and in the pad column)
+  for (int i = tid; i < 3 * kStemIT * kStemIW; i += 256) {
+    const int c = i / (kStemIT * kStemIW), r = i - c * (kStemIT * kStemIW), py = r / kStemIW, px = r - py * kStemIW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float f = 0.f;
+    if (px < kStemIT && iy >= 0 && iy < H && ix >= 0 && ix < W) f = x[((size_t)c * H + iy) * W + ix];
+    s_in[i] = (_Float16)f;
+  }
+  __syncthreads();
+  for (int nt = wave; nt < 10; nt += 4) {
+    const int p = nt * 32 + n;                       // stem pixel of this lane (p >= 289: a spare slot, computed on pixel 288's window, never read)
+    const int pc = p < kStemNpx ? p : kStemNpx - 1;
+    const int sy = pc / kStemST, sx = pc - sy * kStemST;
+    const _Float16* win = s_in + (2 * sy) * kStemIW + 2 * sx;   // window origin: even column -> 4-byte aligned
+    f16x_t acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+      // patch row idx = 2 s + kg -> (c, ky); idx = 21 (kg = 1 of the last step) has zero weights: read row 20 again
+      const int i0 = 2 * s, i1 = 2 * s + 1 < 21 ? 2 * s + 1 : 20;
+      const int off0 = ((i0 / 7) * kStemIT + i0 % 7) * kStemIW, off1 = ((i1 / 7) * kStemIT + i1 % 7) * kStemIW;
+      const unsigned* q = reinterpret_cast<const unsigned*>(win + (kg ? off1 : off0));
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
+      const u4v raw = {q[0], q[1], q[2], q[3]};
+      const h8_t b = __builtin_bit_cast(h8_t, raw);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = mfma32(wf[m][s], b, acc[m]);
+    }
+    // bias + ReLU -> fp16 -> s_st[p][channel]; stem pixels outside the map are 0
+    const int gy = sy0 + sy, gx = sx0 + sx;
+    const bool inside = p < kStemNpx && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = m * 32 + 8 * g + 4 * kg;      // accumulator register 4 g + e is channel row 8 g + 4 kg + e of the M-tile
+        const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+        const float v0 = inside ? fmaxf(acc[m][4 * g + 0] + bv.x, 0.f) : 0.f, v1 = inside ? fmaxf(acc[m][4 * g + 1] + bv.y, 0.f) : 0.f;
+        const float v2 = inside ? fmaxf(acc[m][4 * g + 2] + bv.z, 0.f) : 0.f, v3 = inside ? fmaxf(acc[m][4 * g + 3] + bv.w, 0.f) : 0.f;
+        *reinterpret_cast<h4_t*>(s_st + p * kStemLd + ch) = to_h4(v0, v1, v2, v3);
+      }
+  }
+  __syncthreads();
+  // MaxPool2d(3, 2, 1): pooled pixel (py, px) of the tile = max over stem pixels (2 py + dy, 2 px + dx), dy, dx in 0..2 (tile-local: the
+  // tile's stem origin is one pixel before the first window centre); 8 lanes per pooled pixel -> one whole 128-byte row per pixel
+  for (int i = tid; i < kStemPT * kStemPT * 8; i += 256) {
+    const int pp = i >> 3, cg = i & 7, py = pp / kStemPT, px = pp - py * kStemPT;
+    if (py0 + py >= Hp || px0 + px >= Wp) continue;
+    h8_t mx = *reinterpret_cast<const h8_t*>(s_st + ((2 * py) * kStemST + 2 * px) * kStemLd + cg * 8);
+#pragma unroll
+    for (int d = 1; d < 9; ++d) {
+      const h8_t v = *reinterpret_cast<const h8_t*>(s_st + ((2 * py + d / 3) * kStemST + 2 * px + d % 3) * kStemLd + cg * 8);
+      mx = __builtin_elementwise_max(mx, v);
+    }
+    *reinterpret_cast<h8_t*>(out + ((size_t)(py0 + py) * Wp + px0 + px) * 64 + cg * 8) = mx;
+  }
+}
+void launch_ep_stem_pool(const float* x, int H, int W, int Ho, int Wo, int Hp, int Wp, const _Float16* wfrag, const float* bias, _Float16* out,
+                         hipStream_t s) {
+  const int tiles = ((Hp + kStemPT - 1) / kStemPT) * ((Wp + kStemPT - 1) / kStemPT);
+  hipLaunchKernelGGL(k_ep_stem_pool, dim3(tiles), dim3(256), 0, s, x, H, W, Ho, Wo, Hp, Wp, wfrag, bias, out);
+}
+
 // aggregation tail: per-location L2 normalisation over the 512 channels, GeM(p, eps = 1e-6) over the npix locations, Linear(512 -> 512)
 // (weights transposed [in][out] fp32), L2 normalisation -> fp32 [512].
 // kTailWg = 8 workgroups of 512 threads, TWO launches (round 6).  Round 5 ran both halves in one kernel around a hand-rolled spin barrier in a

@@ -97,6 +97,9 @@ size_t ep_splitk_workspace_bytes(int in_h, int in_w);
 void launch_ep_resize_norm(const uint8_t* src, int stride, int ch, const int* tab, int out_w, int out_h, float* out, hipStream_t s);
 void launch_ep_im2col(const float* x, int H, int W, int Ho, int Wo, _Float16* out, hipStream_t s);
 void launch_ep_maxpool(const _Float16* in, int H, int W, int Ho, int Wo, _Float16* out, hipStream_t s);
+// fused stem + ReLU + max-pool (round 6): wfrag = [2][11][64][8] fp16 A fragments (k = (c, ky, kx padded to 8)), bias fp32 [64]
+void launch_ep_stem_pool(const float* x, int H, int W, int Ho, int Wo, int Hp, int Wp, const _Float16* wfrag, const float* bias, _Float16* out,
+                         hipStream_t s);
 void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* ws, int* counters, float* out,
                     hipStream_t s);
 

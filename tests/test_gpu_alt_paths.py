@@ -332,3 +332,43 @@ def test_winograd_conv2a_conv2b_layer_parity():
         assert "finite True" in r.stdout and "non-finite" not in r.stdout
         for k, v in vals.items():
             assert float(v) < 5e-3, (size, k, v)
+
+
+_EP_WORKER = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/scripts'); import _devlib; _devlib.use_dev_library()
+from superslam_amd import _lib
+from superslam_amd.synth import make_frame
+from superslam_amd.weights import make_eigenplaces_weights, save_safetensors
+_lib.init(0); L = _lib.lib()
+path = {out!r} + '.safetensors'; save_safetensors(make_eigenplaces_weights(2), path)
+res = {{}}
+for (w, h) in ((512, 512), (320, 240), (72, 40), (34, 50)):
+    hd = C.c_void_p(); _lib.check(L.sship_ep_create(path.encode(), w, h, C.byref(hd)))
+    for seed in (3, 4):
+        img = make_frame(376, 1241, seed); d = np.zeros(512, np.float32)
+        _lib.check(L.sship_ep_infer_u8(hd, img.ctypes.data, 376, 1241, 1241, 1, d.ctypes.data))
+        res['%dx%d_%d' % (w, h, seed)] = d
+    L.sship_ep_destroy(hd)
+np.savez({out!r}, **res)
+"""
+
+
+def test_fused_eigenplaces_stem_agrees_with_the_gemm_stem(tmp_path):
+    """k_ep_stem_pool (round 6: 7x7 / stride-2 stem + ReLU + max-pool in one kernel, the patch matrix built in LDS) against the stem of rounds 3-5
+    (im2col -> 1x1 GEMM -> max-pool; developer build, SUPERSLAM_HIP_EP_STEM=gemm).  Same fp16 operands, same rounding points (fp32 accumulate,
+    bias, ReLU, fp16, max); the k order of the accumulation differs ((c, ky, kx) in steps of 16 over kx padded to 8 against the flat 147-tap row),
+    so the descriptors agree to fp32 reassociation through 17 fp16 layers, not bit for bit.  Sizes: the benchmarked 512 x 512, a non-square
+    size with partial pooled tiles, one whose pooled map is smaller than one 8 x 8 tile, and odd extents (odd stem / pooled map sizes)."""
+    outs = {}
+    for name, env in (("fused", {}), ("gemm", {"SUPERSLAM_HIP_EP_STEM": "gemm"})):
+        out = str(tmp_path / ("ep_" + name + ".npz"))
+        code = _EP_WORKER.format(root=ROOT, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=_env(env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    for k in outs["fused"].files:
+        a, b = outs["fused"][k], outs["gemm"][k]
+        dmax, cos = float(np.abs(a - b).max()), float(a @ b)
+        print("EigenPlaces stem fused vs gemm", k, "max|d|", dmax, "cosine", cos)
+        assert np.isfinite(a).all() and dmax <= 1e-3 and cos >= 0.99999, (k, dmax, cos)
