@@ -1810,7 +1810,7 @@ struct sship_ep {
   DevBuf d_in, patches, act[4], d_out;   // patches: the im2col matrix of the GEMM stem (developer build's A/B path only)
   DevBuf stem_frag, stem_bias;           // fused stem (round 6): [2][11][64][8] fp16 A fragments, fp32 bias [64]
   PinBuf h_out;
-  DevBuf d_ws, d_tail;      // split-K partial sums; the tail's [512] pre-normalisation outputs + its arrival counter
+  DevBuf d_ws, d_tail;      // split-K partial sums; the tail's partial GeM sums, [512] pre-normalisation outputs + its arrival counter
   DevBuf d_img;             // u8 entry points: the uploaded image
   PinBuf h_img;
   // resize tables of (src_h, src_w) -> (in_h, in_w), one IMMUTABLE device buffer per source size seen (a dataset has one; a rig a few).
@@ -1911,8 +1911,8 @@ extern "C" int sship_ep_create(const char* weights_path, int input_w, int input_
   SSHIP_HIP_CHECK(ep->d_out.ensure(512 * 4));
   SSHIP_HIP_CHECK(ep->h_out.ensure(512 * 4));
   SSHIP_HIP_CHECK(ep->d_ws.ensure(ep_splitk_workspace_bytes(input_h, input_w)));
-  SSHIP_HIP_CHECK(ep->d_tail.ensure(1026 * 4));
-  SSHIP_HIP_CHECK(hipMemset(ep->d_tail.p, 0, 1026 * 4));
+  SSHIP_HIP_CHECK(ep->d_tail.ensure((ep_tail_ws_floats() + 2) * 4));
+  SSHIP_HIP_CHECK(hipMemset(ep->d_tail.p, 0, (ep_tail_ws_floats() + 2) * 4));
   SSHIP_HIP_CHECK(hipStreamCreateWithFlags(&ep->stream, hipStreamDefault));
   *out = ep.release();
   return SSHIP_OK;
@@ -1958,7 +1958,7 @@ static int ep_network(sship_ep* ep, float* desc_dev, hipStream_t s) {
     SSHIP_HIP_CHECK(ep_conv(blk.c2, a[f[0]], a[f[2]], res, ho, wo, true, false, s, ws, wsb));
     cur = f[2]; h = ho; w = wo;
   }
-  launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, ep->d_tail.as<float>(), ep->d_tail.as<int>() + 1024, desc_dev, s);
+  launch_ep_tail(a[cur], h * w, ep->gem_p, ep->fc_wt, ep->fc_b, ep->d_tail.as<float>(), ep->d_tail.as<int>() + ep_tail_ws_floats(), desc_dev, s);
   SSHIP_HIP_CHECK(hipGetLastError());
   return SSHIP_OK;
 }

@@ -364,70 +364,72 @@ void launch_ep_stem_pool(const float* x, int H, int W, int Ho, int Wo, int Hp, i
 // tracker's persistent conv kernels, exactly where 8 workgroups need not start together, and an aborted call left the barrier counter poisoned
 // (ADVICE r05).  The Linear needs all 512 pooled values, so the kernel boundary IS the barrier: ~1.5 us of launch gap instead
 // of a spin that can last a whole foreign kernel.
-//   k_ep_tail_pool: (1) every workgroup computes the inverse norms of all locations (a wave per location, four locations in flight: one
-//     coalesced 1-KB row each, wave_sum); (2) workgroup g pools ITS 64 channels, thread = (channel, 1/8 of the locations), and publishes them.
-//     It also zeroes the arrival counter of the second kernel, so a previous call that died mid-way cannot poison this one.
-//   k_ep_tail_fc: (3) workgroup g computes its 64 outputs, thread = (1/8 of the inputs, output): 128 KB of weights per workgroup; (4) the last
-//     workgroup to ARRIVE (an atomic ticket - nobody waits) normalises.
+//   k_ep_tail_pool (second form of round 6): ONE pass over the map by up to kTailPoolWg workgroups.  A wave owns a location at a time: one coalesced
+//     1-KB row (8 channels per lane), wave_sum -> inverse norm, then clamp(x / ||x||, 1e-6)^p of its 8 channels accumulated in registers.  The
+//     workgroup adds its 8 waves' sums in wave order and publishes [512] partial sums; the partials are added in workgroup order by the second
+//     kernel - one fixed summation order for a given map size.  (The first form had each of 8 workgroups recompute all inverse norms and then
+//     walk its 64 channels with 2-byte strided loads: 16.7 us for a 256-KB map.)  It also zeroes the arrival counter of the second kernel, so a
+//     previous call that died mid-way cannot poison this one.
+//   k_ep_tail_fc: (3) every workgroup finishes the GeM of all 512 channels ((mean)^(1/p): 512 threads, one channel each), then computes its 64
+//     outputs, thread = (1/8 of the inputs, output) with its 64 weights all in flight: 128 KB of weights per workgroup; (4) the last workgroup
+//     to ARRIVE (an atomic ticket - nobody waits) normalises.
 constexpr int kTailWg = 8;
-__global__ __launch_bounds__(512) void k_ep_tail_pool(const _Float16* __restrict__ feat, int npix, float p, float* __restrict__ g_ws,
+constexpr int kTailPoolWg = 32;
+static int ep_tail_pool_wgs(int npix) { const int g = (npix + 7) / 8; return g < kTailPoolWg ? g : kTailPoolWg; }  // a function of the map size only
+__global__ __launch_bounds__(512) void k_ep_tail_pool(const _Float16* __restrict__ feat, int npix, float p, float* __restrict__ g_part,
                                                       int* __restrict__ counters) {
-  extern __shared__ float s_ep[];  // [npix] inverse norms | [512] partials
-  float* s_inv = s_ep;
-  float* s_part = s_ep + npix;
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = blockIdx.x;
+  __shared__ float s_part[8 * 512];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = blockIdx.x, G = gridDim.x;
   if (g == 0 && t == 0) counters[0] = 0;  // k_ep_tail_fc's ticket (stream-ordered after this kernel)
-  // (1) inverse norms: F.normalize(dim = channels): x / max(||x||, 1e-12)
-  for (int px0 = wave * 4; px0 < npix; px0 += 32) {
-    h8_t v[4];
+  float acc[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8_t*>(feat + (size_t)min(px0 + u, npix - 1) * 512 + lane * 8);
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int px = g * 8 + wave; px < npix; px += 8 * G) {
+    const h8_t v = *reinterpret_cast<const h8_t*>(feat + (size_t)px * 512 + lane * 8);
+    float ss = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float ss = 0.f;
+    for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+    ss = wave_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize(dim = channels): x / max(||x||, 1e-12)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ss = fmaf((float)v[u][e], (float)v[u][e], ss);
-      ss = wave_sum(ss);
-      if (lane == 0 && px0 + u < npix) s_inv[px0 + u] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int e = 0; e < 8; ++e) {
+      const float x = fmaxf((float)v[e] * inv, 1e-6f);
+      acc[e] += __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));  // x in [1e-6, 1]: no denormal handling needed (v_log_f32 / v_exp_f32)
     }
   }
+  *reinterpret_cast<float4*>(s_part + wave * 512 + lane * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(s_part + wave * 512 + lane * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
   __syncthreads();
-  // (2) GeM of channels [64 g, 64 g + 64): (mean over locations of clamp(x, 1e-6)^p)^(1/p); thread (c, q) sums locations q, q + 8, ...
-  const int c = 64 * g + lane;
-  float acc = 0.f;
-  for (int px0 = wave; px0 < npix; px0 += 64) {  // eight locations in flight per thread (one dependent 2-byte load at a time was most of the kernel)
-    _Float16 v[8];
+  float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = feat[(size_t)min(px0 + 8 * u, npix - 1) * 512 + c];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int px = px0 + 8 * u;
-      const float x = fmaxf((float)v[u] * s_inv[min(px, npix - 1)], 1e-6f);
-      const float e = __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));  // x in [1e-6, 1]: no denormal handling needed (v_log_f32 / v_exp_f32)
-      acc += px < npix ? e : 0.f;
-    }
-  }
-  s_part[t] = acc;
-  __syncthreads();
-  if (t < 64) {
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sum += s_part[q * 64 + t];  // ascending location group: one fixed summation order
-    g_ws[64 * g + t] = exp2f(log2f(sum / (float)npix) / p);
-  }
+  for (int q = 0; q < 8; ++q) sum += s_part[q * 512 + t];  // ascending wave: one fixed summation order
+  g_part[(size_t)g * 512 + t] = sum;
 }
-__global__ __launch_bounds__(512) void k_ep_tail_fc(const float* __restrict__ g_ws, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                    float* __restrict__ y_ws, int* __restrict__ counters, float* __restrict__ out) {
+__global__ __launch_bounds__(512) void k_ep_tail_fc(const float* __restrict__ g_part, int nparts, int npix, float p, const float* __restrict__ wt,
+                                                    const float* __restrict__ bias, float* __restrict__ y_ws, int* __restrict__ counters,
+                                                    float* __restrict__ out) {
   __shared__ float s_g[512], s_part[512], s_red[8];
   __shared__ int s_last;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = blockIdx.x;
-  s_g[t] = g_ws[t];  // written by the previous kernel: visible at the kernel boundary
-  __syncthreads();
-  // (3) Linear: outputs [64 g, 64 g + 64); thread (part, output) covers inputs [64 part, 64 part + 64)
+  // (3) Linear: outputs [64 g, 64 g + 64); thread (part, output) covers inputs [64 part, 64 part + 64): its weights first (independent of the
+  // pooled values: the 64 loads overlap the partial-sum reads), then the GeM of channel t
   const int j = 64 * g + lane, part = wave;
+  float wv[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) wv[c] = wt[(size_t)(part * 64 + c) * 512 + j];
+  {
+    float pv[kTailPoolWg];   // all partial sums in flight (a loop over a run-time count waits for one L2 round trip per partial: 16 us)
+#pragma unroll
+    for (int q = 0; q < kTailPoolWg; ++q) pv[q] = q < nparts ? g_part[(size_t)q * 512 + t] : 0.f;  // written by the previous kernel: visible at the kernel boundary
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < kTailPoolWg; ++q) sum += pv[q];  // ascending workgroup order; the unused rows add +0
+    s_g[t] = exp2f(log2f(sum / (float)npix) / p);  // GeM: (mean over locations of clamp(x, 1e-6)^p)^(1/p)
+  }
+  __syncthreads();
   float d = 0.f;
-#pragma unroll 8
-  for (int c = part * 64; c < part * 64 + 64; ++c) d = fmaf(wt[(size_t)c * 512 + j], s_g[c], d);
+#pragma unroll
+  for (int c = 0; c < 64; ++c) d = fmaf(wv[c], s_g[part * 64 + c], d);
   s_part[t] = d;
   __syncthreads();
   if (t < 64) {
@@ -452,11 +454,14 @@ __global__ __launch_bounds__(512) void k_ep_tail_fc(const float* __restrict__ g_
   for (int w = 0; w < 8; ++w) tot += s_red[w];
   out[t] = y / fmaxf(sqrtf(tot), 1e-12f);
 }
-// ws: [1024] floats, counters: [>= 1] int (any value: the first kernel resets it).  Calls of one handle are stream-ordered (include/sship.h).
+// ws: [kTailPoolWg * 512 partial sums | 512 pre-normalisation outputs] floats (sship_ep_tail_ws_floats), counters: [>= 1] int (any value: the first
+// kernel resets it).  Calls of one handle are stream-ordered (include/sship.h).
+size_t ep_tail_ws_floats() { return (size_t)kTailPoolWg * 512 + 512; }
 void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* ws, int* counters, float* out,
                     hipStream_t s) {
-  hipLaunchKernelGGL(k_ep_tail_pool, dim3(kTailWg), dim3(512), (size_t)(npix + 512) * 4, s, feat, npix, p, ws, counters);
-  hipLaunchKernelGGL(k_ep_tail_fc, dim3(kTailWg), dim3(512), 0, s, ws, wt, bias, ws + 512, counters, out);
+  const int G = ep_tail_pool_wgs(npix);
+  hipLaunchKernelGGL(k_ep_tail_pool, dim3(G), dim3(512), 0, s, feat, npix, p, ws, counters);
+  hipLaunchKernelGGL(k_ep_tail_fc, dim3(kTailWg), dim3(512), 0, s, ws, G, npix, p, wt, bias, ws + (size_t)kTailPoolWg * 512, counters, out);
 }
 
 }  // namespace sship

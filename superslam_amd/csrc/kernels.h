@@ -100,6 +100,7 @@ void launch_ep_maxpool(const _Float16* in, int H, int W, int Ho, int Wo, _Float1
 // fused stem + ReLU + max-pool (round 6): wfrag = [2][11][64][8] fp16 A fragments (k = (c, ky, kx padded to 8)), bias fp32 [64]
 void launch_ep_stem_pool(const float* x, int H, int W, int Ho, int Wo, int Hp, int Wp, const _Float16* wfrag, const float* bias, _Float16* out,
                          hipStream_t s);
+size_t ep_tail_ws_floats();   // the tail's workspace: partial GeM sums of up to 32 workgroups + the [512] pre-normalisation outputs
 void launch_ep_tail(const _Float16* feat, int npix, float p, const float* wt, const float* bias, float* ws, int* counters, float* out,
                     hipStream_t s);
 
