@@ -350,7 +350,8 @@ int sship_get_stage_timings(const char** labels, float* ms, int max_stages);
  * 11 convDb.  *macs receives the layer's multiply-accumulate count for that shape. */
 int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms, double* macs);
 /* (layer ids 12-14 are the memory-bound stages of the same handle: 12 = softmax + depth-to-space + NMS + threshold +
- * candidate compaction, 13 = top-k, 14 = descriptor head at the selected keypoints; *macs = 0 for them.)
+ * candidate compaction, 13 = top-k, 14 = descriptor head at the selected keypoints; *macs = 0 for them.
+ * 15 = conv2a + conv2b + pool as the ONE launch throughput batches run instead of layers 2 and 3 (csrc/conv_fuse2.hip; *macs = both layers').)
  *
  * Same for one stage of the matcher, over the state the last match call left on this handle, timed with hipEvents on the
  * handle's stream: 0 first Wqkv projection, 1 self attention, 2 cross attention (both directions), 3 SelfBlock FFN + the

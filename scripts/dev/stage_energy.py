@@ -4,7 +4,7 @@ build of it - the unit every kernel experiment of round 6 is priced in (the call
 
   python scripts/dev/stage_energy.py [--library lib/variants/x.so] [--sp 5,6,8] [--lg 1,2,3,4] [--seconds 1.0] [--tag name] [--kp 600]
 SuperPoint layer ids (sship_sp_bench_layer): 1 conv1a+1b+pool, 2 conv2a, 3 conv2b+pool, 4 conv3a, 5 conv3b+pool, 6 conv4a, 7 conv4b, 8 convPa,
-9 convPb, 12 k_nms_tile, 13 k_topk, 14 descriptor head.  LightGlue stage ids (sship_lg_bench_stage): 0 first Wqkv, 1 self attention, 2 cross
+9 convPb, 12 k_nms_tile, 13 k_topk, 14 descriptor head, 15 conv2a + conv2b + pool fused (conv_fuse2.hip).  LightGlue stage ids (sship_lg_bench_stage): 0 first Wqkv, 1 self attention, 2 cross
 attention, 3 SelfBlock FFN (+ to_qk | to_v), 4 CrossBlock FFN (+ Wqkv), 5 last FFN + final_proj, 6 / 7 assignment passes.
 Prints one JSON line: {tag, library, rows: [{stage, launch_us, avg_W, sclk_MHz, joules_per_launch, samples}]}.
 """
@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 SP_NAMES = {1: "conv1a+conv1b+pool", 2: "conv2a", 3: "conv2b+pool", 4: "conv3a", 5: "conv3b+pool", 6: "conv4a", 7: "conv4b", 8: "convPa", 9: "convPb",
-            12: "k_nms_tile", 13: "k_topk", 14: "k_desc_head_sparse"}
+            12: "k_nms_tile", 13: "k_topk", 14: "k_desc_head_sparse", 15: "conv2a+conv2b+pool (fused)"}
 LG_NAMES = {0: "lg_wqkv0", 1: "lg_self_attention", 2: "lg_cross_attention", 3: "lg_self_ffn", 4: "lg_cross_ffn", 5: "lg_last_ffn", 6: "lg_assign1", 7: "lg_assign2"}
 
 

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsuperslam_hip.so")
 # The shipped library: ONE kernel per layer, no run-time kernel selection (include/sship.h, "Environment").
-SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_pp.hip", "conv_pp128.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
+SOURCES = ["api.hip", "sp_kernels.hip", "sp_convs.hip", "conv_pp.hip", "conv_pp128.hip", "conv_fuse2.hip", "lg_kernels.hip", "ep_kernels.hip", "probe.hip", "shard_rccl.hip"]
 # Developer build (lib/variants/dev.so, -DSSHIP_DEV_SWITCHES=1): the same sources with the A/B switches and phase traces compiled in, plus
 # the rejected kernels they select: the lock-step strip conv (r01), Winograd conv2a/2b (r04: -25 %), the 16-wave FFN (r04: +-0), the
 # LDS-resident-key attention (r05: -8 %).  tests/test_gpu_alt_paths.py and scripts/dev/* load it explicitly (superslam_amd._lib.set_library_path via scripts/_devlib.py).

@@ -675,6 +675,17 @@ static hipError_t conv3(const ConvW& w, const _Float16* in, _Float16* out, int B
   return sp_conv3x3_pp(w, in, out, B, H, W, pool, s);
 #endif
 }
+// conv2a + conv2b + pool as one launch (conv_fuse2.hip) when the batch fills the chip with strip segments; the developer build's
+// SUPERSLAM_HIP_CONV2 = split / fused forces either path (A/B, and the fused kernel on small frames in tests/test_gpu_alt_paths.py)
+static bool conv2_fused(int B, int H2, int W2) {
+#if SSHIP_DEV_SWITCHES
+  static const std::string mode = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV2"); return std::string(e ? e : ""); }();
+  static const bool other = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV64"); return e != nullptr; }();
+  if (mode == "split" || other || conv_mode() != 1) return false;
+  if (mode == "fused") return sp_conv2ab_fused_fits(B, H2, W2, true);
+#endif
+  return sp_conv2ab_fused_fits(B, H2, W2, false);
+}
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s);
 static bool desc_dense_mode() {
   static const bool v = [] { const char* e = dev_env("SUPERSLAM_HIP_DESC"); return e && std::string(e) == "dense"; }();
@@ -704,10 +715,16 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
   // carries the bare level-1 label: a stage's level-1 time is the SUM over its "<label>/..." entries (what bench.py does)
   SSHIP_HIP_CHECK(conv1ab(sp, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
   g_timer.mark_fine("sp_gpu_infer:encoder/conv1a+conv1b+pool", s);
-  SSHIP_HIP_CHECK(conv3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));
-  g_timer.mark_fine("sp_gpu_infer:encoder/conv2a", s);
-  SSHIP_HIP_CHECK(conv3(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, s));
-  g_timer.mark_fine("sp_gpu_infer:encoder/conv2b+pool", s);
+  if (conv2_fused(B, H2, W2)) {
+    // throughput batches: conv2a -> conv2b -> pool in one launch, the map between them never leaves the CU (conv_fuse2.hip; bit-identical)
+    SSHIP_HIP_CHECK(sp_conv2ab_fused(sp->c2a, sp->c2b, sp->a1b.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, s));
+    g_timer.mark_fine("sp_gpu_infer:encoder/conv2a+conv2b+pool", s);
+  } else {
+    SSHIP_HIP_CHECK(conv3(sp->c2a, sp->a1b.as<_Float16>(), sp->a2a.as<_Float16>(), B, H2, W2, false, s));
+    g_timer.mark_fine("sp_gpu_infer:encoder/conv2a", s);
+    SSHIP_HIP_CHECK(conv3(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, s));
+    g_timer.mark_fine("sp_gpu_infer:encoder/conv2b+pool", s);
+  }
   SSHIP_HIP_CHECK(conv3(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, s));
   g_timer.mark_fine("sp_gpu_infer:encoder/conv3a", s);
   SSHIP_HIP_CHECK(conv3(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, s));
@@ -942,7 +959,7 @@ extern "C" int sship_mfma_probe(int random_operands, float* tflops) {
 extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, int w, int iters, float* avg_ms,
                                     double* macs) {
   bind_thread();
-  if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 14) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");
+  if (!sp || !avg_ms || iters <= 0 || layer < 0 || layer > 15) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: bad arguments");
   if (batch > sp->wsB || h != sp->wsH || w != sp->wsW) return fail(SSHIP_ERR_INVALID, "sp_bench_layer: run the network at this shape first");
   if (layer <= 1 && !sp->img_valid)
     return fail(SSHIP_ERR_INVALID, "sp_bench_layer: the handle holds no copy of the last input - make one call with sship_set_profiling(1) first "
@@ -958,6 +975,9 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
     switch (layer) {
       case 0: launch_conv1a(sp->img.as<uint8_t>(), sp->w1a, sp->b1a, a1a, batch, h, w, s); return hipGetLastError();  // stand-alone (not on the path)
       case 1: return conv1ab(sp, sp->img.as<uint8_t>(), a1b, batch, h, w, s);
+      case 15:  // conv2a -> conv2b -> pool in one launch (conv_fuse2.hip): what a throughput batch runs instead of layers 2 and 3
+        if (!sp_conv2ab_fused_fits(batch, H2, W2, true)) return hipErrorInvalidValue;
+        return sp_conv2ab_fused(sp->c2a, sp->c2b, a1b, a2b, batch, H2, W2, s);
       case 2: return conv3(sp->c2a, a1b, a2a, batch, H2, W2, false, s);
       case 3: return conv3(sp->c2b, a2a, a2b, batch, H2, W2, true, s);
       case 4: return conv3(sp->c3a, a2b, a3a, batch, H4, W4, false, s);
@@ -994,7 +1014,7 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
                          (size_t)sp->cfg.max_keypoints * 256, s);
     }
   };
-  if (layer >= 13) {  // these read the selection's outputs: produce them once on this handle's own buffers
+  if (layer == 13 || layer == 14) {  // these read the selection's outputs: produce them once on this handle's own buffers
     const int keep = layer;
     layer = 12; SSHIP_HIP_CHECK(run());
     layer = 13; SSHIP_HIP_CHECK(run());
@@ -1004,7 +1024,7 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
                          (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc, (double)Hc * Wc};
   const double mpp[12] = {9.0 * 64, 576.0 * 64 + 9.0 * 64 /* conv1a fused */, 576.0 * 64, 576.0 * 64, 576.0 * 128, 1152.0 * 128, 1152.0 * 128,
                           1152.0 * 128, 1152.0 * 256, 256.0 * 65, 1152.0 * 256, 256.0 * 256};
-  if (macs) *macs = layer < 12 ? px[layer] * mpp[layer] * batch : 0.0;
+  if (macs) *macs = layer < 12 ? px[layer] * mpp[layer] * batch : layer == 15 ? (px[2] * mpp[2] + px[3] * mpp[3]) * batch : 0.0;
   SSHIP_HIP_CHECK(run());  // warm
   hipEvent_t e0, e1;
   SSHIP_HIP_CHECK(hipEventCreate(&e0));

@@ -1,0 +1,284 @@
+// conv2a -> conv2b -> 2x2 max-pool of SuperPoint (utils/convert_superpoint_to_onnx.py:40-43, 53-55) as ONE kernel: the 64-channel half-resolution
+// map between the two layers never leaves the CU.
+//
+// Why (profiles/r06_d_conv_store_energy.txt): on the 1 400 W cap a launch's time is its joules, and 34 % of conv2a's joules are its OUTPUT STORES
+// (2.1 GB per 128-image launch at 120-270 pJ per byte written; the store pattern, the store order and cache blocking do not move it).  conv2b then
+// reads the same 2.1 GB back.  Fusing the pair trades that round trip for a one-pixel halo of recomputed conv2a columns.
+//
+// How: a ROLLING WINDOW down a 30-column strip instead of 2-D tiles, so that only the horizontal halo is recomputed (32 / 30 on conv2a, two idle
+// lanes of 32 on conv2b; a tile scheme at 8 x 32 would recompute 33 %), and both layers' intermediate state is a ring of 12 rows each:
+//   * a workgroup is 8 waves = two per SIMD: waves 0-3 are conv2a (PRODUCERS), waves 4-7 conv2b (CONSUMERS).  Wave (m, rp) of a role owns the M-tile m
+//     (32 output channels) of the row pair rp of a 4-row step: two 32-pixel N-tiles, 2 x 36 MFMAs 32x32x16 per step.
+//   * the WEIGHTS live in registers: a wave only ever needs its layer's M-tile m = 36 A fragments = 144 VGPRs, loaded once per launch (the kernel
+//     is persistent).  That frees the 144 KiB of LDS the two layers' weights would need, which is what made the fusion impossible as a tile kernel
+//     (conv_pp.hip holds ONE layer's 72 KiB next to two 43-KiB tiles), and removes the A-fragment LDS reads: one ds_read_b128 per MFMA is left.
+//   * slot t of the pipeline: the producers compute intermediate rows 4t-1 .. 4t+2 of the strip from the INPUT ring into the MID ring, the consumers
+//     compute output rows 4(t-2) .. 4(t-2)+3 from the MID ring (rows produced in slots <= t-1), pool them and store; all waves issue the LDS-DMA
+//     (buffer_load_dwordx4 ... lds) of the four input rows of slot t+2.  One workgroup barrier per slot; the two roles on a SIMD are both MFMA streams
+//     whose fragment reads, epilogues and stores ride under the other's MFMAs.
+//   * ring rows: 34 pixels x 144 B (64 channels + 16 B pad: conflict-free ds_read_b128 with a PLAIN layout, so a fragment address is one per-row
+//     VGPR base plus an immediate) in 5 120 B = 5 DMA instructions; out-of-image pixels get their voffset pushed out of the buffer's range and the DMA
+//     writes zeros (scripts/ubench/lds_dma_oob.hip).  conv2b's zero padding is on conv2a's OUTPUT: the producers write zeros for intermediate pixels
+//     outside the image.
+//   * same fp16 operands, same k order per accumulator (tap-major, four k-steps per tap, accumulator started from the bias), same rounding points as
+//     conv3x3_pp<64, 64, ...>: the output is BIT-IDENTICAL to the two-launch path (tests/test_gpu_alt_paths.py, tests/test_gpu_bench_batch_parity.py),
+//     which the library keeps for batches too small to fill the chip with strips.
+// LDS: 2 x 12 x 5 120 B rings + 512 B bias = 123.4 KB, one workgroup per CU.
+#include "common.h"
+#include "kernels.h"
+
+namespace sship {
+
+struct F2Args {
+  const _Float16* in;    // channels-last fp16 [B,H,W,64]
+  const _Float16* wa;    // conv2a packed weights [tap][kstep][mt 2][lane][8] (igemm.h packing, ct = 64)
+  const float* ba;
+  const _Float16* wb;    // conv2b
+  const float* bb;
+  _Float16* out;         // [B,H/2,W/2,64]
+  int B, H, W;
+  int nstrips, nseg, H4; // strips per image row, row segments per strip, 4-row steps per strip
+  int nunits;            // B * nstrips * nseg
+};
+
+constexpr int F_TW = 30;                  // output columns per strip
+constexpr int F_PXB = 144;                // bytes per ring pixel
+constexpr int F_ROWB = 5120;              // bytes per ring row
+constexpr int F_RING = 12;                // rows per ring
+constexpr int F_RINGB = F_RING * F_ROWB;  // 61 440
+constexpr unsigned F_OOB = 0x80000000u;   // beyond num_records, and no 32-bit wrap with soffset on top
+constexpr size_t F_SMEM = 2 * F_RINGB + 2 * 64 * 4;
+
+struct F2Walk { int u, k, S, b, s, r0; };  // wave-uniform: unit, step inside the unit (0 .. S), steps of the unit, image, strip, first row
+
+__global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
+  extern __shared__ __attribute__((aligned(16))) char f2_smem[];
+  char* s_in = f2_smem;
+  char* s_mid = f2_smem + F_RINGB;
+  float* s_bias = reinterpret_cast<float*>(f2_smem + 2 * F_RINGB);  // [role][64]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, gw = wave & 3, m = gw & 1, rp = gw >> 1;
+  const int Ho = p.H >> 1, Wo = p.W >> 1;
+
+  if (tid < 128) s_bias[tid] = tid < 64 ? p.ba[tid] : p.bb[tid - 64];
+  // this wave's 36 A fragments (M-tile m of its layer), for the whole launch
+  h8_t wreg[36];
+  {
+    const _Float16* w = (role ? p.wb : p.wa) + m * 512 + lane * 8;
+#pragma unroll
+    for (int idx = 0; idx < 36; ++idx) wreg[idx] = *reinterpret_cast<const h8_t*>(w + idx * 1024);
+  }
+
+  const int u_begin = (int)((long long)blockIdx.x * p.nunits / gridDim.x), u_end = (int)((long long)(blockIdx.x + 1) * p.nunits / gridDim.x);
+  if (u_begin >= u_end) return;
+  auto decode = [&](F2Walk& w) __attribute__((always_inline)) {
+    const int seg = w.u % p.nseg, t = w.u / p.nseg;
+    w.s = t % p.nstrips; w.b = t / p.nstrips;
+    const int k0 = seg * p.H4 / p.nseg, k1 = (seg + 1) * p.H4 / p.nseg;
+    w.r0 = 4 * k0; w.S = k1 - k0; w.k = 0;
+  };
+  auto advance = [&](F2Walk& w) __attribute__((always_inline)) {
+    if (++w.k > w.S) {
+      ++w.u;
+      if (w.u < u_end) decode(w);
+    }
+  };
+  int Q = 0;  // pipeline steps of this workgroup: S + 1 per unit
+  {
+    F2Walk w; w.u = u_begin;
+    for (; w.u < u_end; ++w.u) { decode(w); Q += w.S + 1; }
+  }
+
+  // ---------------- LDS-DMA of one load step: input rows r0 - 2 + 4k + i (i = 0..3), columns 30 s - 2 .. 30 s + 31, into ring rows (4 q + i) % 12 ----------------
+  // instruction n = 5 i + c (c = 0..4) of a step writes LDS units 64 c .. 64 c + 63 of ring row i; wave w issues n = w, w + 8, w + 16 (< 20).
+  // unit p = 64 c + lane of a row is pixel p / 9, 16-byte channel unit p % 9 (unit 8 = the pad, units >= 306 = the row's tail: zeros)
+  int d_i[3], d_c[3], d_px[3];
+  unsigned d_voff[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int n = wave + 8 * e;
+    d_i[e] = n / 5; d_c[e] = n - 5 * d_i[e];
+    const int pu = d_c[e] * 64 + lane, px = pu / 9, un = pu - 9 * px;
+    d_px[e] = (pu < 306 && un < 8) ? px : 1000;  // 1000: never inside the column window
+    d_voff[e] = (unsigned)((d_i[e] * p.W + px) * 128 + un * 16);
+  }
+  const int n_dma = wave < 4 ? 3 : 2;
+  typedef int rsrc4_t __attribute__((ext_vector_type(4)));
+  auto dma_step = [&](const F2Walk& w, int q3) __attribute__((always_inline)) {
+    // buffer of image b, based two rows and two pixels before it: offsets stay non-negative and 32-bit
+    const unsigned long long ba = (unsigned long long)(uintptr_t)p.in + ((unsigned long long)w.b * p.H * p.W - (unsigned long long)(2 * p.W + 2)) * 128ull;
+    rsrc4_t rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ba);
+    rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba >> 32) & 0xffffu));
+    rs[2] = 0x7ffffff0;
+    rs[3] = 0x00020000;
+    const int row0 = w.r0 + 4 * w.k;  // image row of i = 0 is row0 - 2
+    const unsigned soff = (unsigned)((row0 * p.W + F_TW * w.s) * 128);
+    const int pxlo = w.s == 0 ? 2 : 0, pxhi = min(34, p.W - F_TW * w.s + 2);  // ring pixel px is image column 30 s - 2 + px
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if (e >= n_dma) break;
+      const int ri = row0 - 2 + d_i[e];
+      const bool rowok = ri >= 0 && ri < p.H;
+      const unsigned v = (rowok && d_px[e] >= pxlo && d_px[e] < pxhi) ? d_voff[e] : F_OOB;
+      int rr = 4 * q3 + d_i[e];
+      rr = rr >= F_RING ? rr - F_RING : rr;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(s_in + rr * F_ROWB + d_c[e] * 1024));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(v), "s"(m0v), "s"(rs), "s"(soff) : "memory");
+    }
+  };
+
+  // ---------------- one 4-row step of this wave's layer: 2 N-tiles (rows 2 rp, 2 rp + 1 of the step) x 36 k-steps ----------------
+  const unsigned lane_b = (unsigned)(j * F_PXB + hh * 16);
+  f16x_t acc[2];
+  auto mfma_step = [&](int q3) __attribute__((always_inline)) {
+    const char* ring = role ? s_mid : s_in;
+    // ring rows 4 q3 + 2 rp + d (d = 0..3) hold the rows this wave's two N-tiles read (tap row ky of N-tile n: d = n + ky)
+    const char* rb[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      int rr = 4 * q3 + 2 * rp + d;
+      rr = rr >= F_RING ? rr - F_RING : rr;
+      rb[d] = ring + rr * F_ROWB + lane_b;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + role * 64 + m * 32 + hh * 4 + g * 8);
+        acc[n][4 * g + 0] = b4.x; acc[n][4 * g + 1] = b4.y; acc[n][4 * g + 2] = b4.z; acc[n][4 * g + 3] = b4.w;
+      }
+    constexpr int NBUF = 3;
+    h8_t fb[NBUF][2];
+    auto load_frags = [&](int idx, int buf) __attribute__((always_inline)) {
+      const int tap = idx >> 2, ky = tap / 3, kx = tap - 3 * ky, ks = idx & 3;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) fb[buf][n] = *reinterpret_cast<const h8_t*>(rb[n + ky] + kx * F_PXB + ks * 32);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) load_frags(i, i);
+#pragma unroll
+    for (int idx = 0; idx < 36; ++idx) {
+      if (idx + NBUF - 1 < 36) load_frags(idx + NBUF - 1, (idx + NBUF - 1) % NBUF);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[n] = mfma32(wreg[idx], fb[idx % NBUF][n], acc[n]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // conv2a epilogue: ReLU -> fp16 -> MID ring row (4 q3 + 2 rp + n) % 12, pixel j (image column 30 s - 1 + j), channels 32 m + 8 g + 4 hh .. + 3
+  auto epi_producer = [&](const F2Walk& w, int q3) __attribute__((always_inline)) {
+    const int col = F_TW * w.s - 1 + j;
+    const bool colok = col >= 0 && col < p.W;
+    const h4_t z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int ri = w.r0 - 1 + 4 * w.k + 2 * rp + n;
+      const bool ok = colok && ri >= 0 && ri < p.H;
+      int rr = 4 * q3 + 2 * rp + n;
+      rr = rr >= F_RING ? rr - F_RING : rr;
+      char* dst = s_mid + rr * F_ROWB + j * F_PXB + m * 64 + hh * 8;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4_t o = __builtin_elementwise_max(to_h4(acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]), z4);
+        if (!ok) o = z4;
+        *reinterpret_cast<h4_t*>(dst + g * 16) = o;
+      }
+    }
+  };
+  // conv2b epilogue: ReLU + 2x2 max-pool of this wave's row pair -> fp16 -> global, one 16-byte store per (even pixel, 8-channel unit).
+  // It runs at the START of the consumers' next slot (the accumulators and the store address are carried over): the producers are then in their
+  // MFMA loop and the consumers' stores have the whole slot to be acknowledged; the producers' epilogue closes THEIR slot while the consumers are
+  // still in their MFMA loop.  In lock-step (both epilogues at the end of the slot) the matrix pipe idled for both.
+  _Float16* pend_pix = nullptr;
+  bool pend_ok = false;
+  auto prep_consumer = [&](const F2Walk& w) __attribute__((always_inline)) {
+    const int yo = (w.r0 + 4 * w.k + 2 * rp) >> 1, xo = (F_TW / 2) * w.s + (j >> 1);
+    pend_ok = yo < Ho && !(j & 1) && j < F_TW && xo < Wo;
+    pend_pix = p.out + ((size_t)(w.b * Ho + yo) * Wo + xo) * 64 + m * 32 + hh * 8;
+  };
+  auto epi_consumer = [&]() __attribute__((always_inline)) {
+    auto pool1 = [&](int r) __attribute__((always_inline)) -> float {  // max over the two rows and 0 (v_max3), then the column pair (dpp quad_perm [1,0,3,2])
+      const float tt = fmaxf(fmaxf(acc[0][r], acc[1][r]), 0.f);
+      const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tt), 0xB1, 0xF, 0xF, false));
+      return fmaxf(tt, nb);
+    };
+    auto pack2 = [](float lo, float hi) __attribute__((always_inline)) -> unsigned {
+      const h2_t v = {(_Float16)lo, (_Float16)hi};
+      return *reinterpret_cast<const unsigned*>(&v);
+    };
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      // lanes hh = 0 / 1 hold channels 4 hh .. + 3 of an 8-channel unit: permlane32_swap pairs them, lane hh stores unit g + hh
+      const auto r0 = __builtin_amdgcn_permlane32_swap(pack2(pool1(4 * g + 0), pool1(4 * g + 1)), pack2(pool1(4 * g + 4), pool1(4 * g + 5)), false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(pack2(pool1(4 * g + 2), pool1(4 * g + 3)), pack2(pool1(4 * g + 6), pool1(4 * g + 7)), false, false);
+      if (pend_ok) *reinterpret_cast<uint4*>(pend_pix + g * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+  };
+
+  // ---------------- schedule: slot t = DMA of load step t + 2 | producer step t | consumer step t - 2, one barrier ----------------
+  F2Walk wd, wr;
+  wd.u = u_begin; decode(wd);
+  wr = wd;
+  int qd3 = 0;  // (DMA step index) % 3
+  dma_step(wd, qd3); advance(wd); qd3 = 1;
+  if (wd.u < u_end) { dma_step(wd, qd3); advance(wd); }
+  qd3 = 2;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int lag = role ? 2 : 0;
+  int q3 = 0;  // (this role's step index) % 3
+  bool pending = false;  // consumers: the previous step's accumulators wait for their epilogue
+#pragma unroll 1
+  for (int t = 0; t < Q + 2; ++t) {
+    if (wd.u < u_end) { dma_step(wd, qd3); advance(wd); }
+    qd3 = qd3 == 2 ? 0 : qd3 + 1;
+    if (pending) { epi_consumer(); pending = false; }
+    const int q = t - lag;
+    if (q >= 0 && q < Q) {
+      // producers: the last step of a unit (k = S) only makes rows r1 - 1, r1 (row pair 0); consumers: it is empty
+      const bool active = role == 0 ? (wr.k < wr.S || rp == 0) : wr.k < wr.S;
+      if (active) {
+        mfma_step(q3);
+        if (role == 0) epi_producer(wr, q3);
+        else { prep_consumer(wr); pending = true; }
+      }
+      advance(wr);
+      q3 = q3 == 2 ? 0 : q3 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (pending) epi_consumer();
+}
+
+bool sp_conv2ab_fused_fits(int B, int H, int W, bool any_batch) {
+  if (H < 8 || W < 8 || B < 1) return false;
+  if ((size_t)H * W * 128 >= 0x7f000000ull) return false;  // offsets inside one image are 32-bit
+  const int nstrips = (W + F_TW - 1) / F_TW, H4 = (H + 3) / 4;
+  const int nseg = H4 >= 16 ? 2 : 1;
+  // throughput batches only: every CU gets several strip segments (a pair of frames is 92 segments on 256 CUs: the two-launch path is faster there)
+  return any_batch || (long long)B * nstrips * nseg >= 4ll * cu_count();
+}
+
+hipError_t sp_conv2ab_fused(const ConvW& wa, const ConvW& wb, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s) {
+  if (wa.cin != 64 || wa.cout != 64 || wa.ct != 64 || wb.cin != 64 || wb.cout != 64 || wb.ct != 64) return hipErrorInvalidValue;
+  F2Args a{};
+  a.in = in; a.wa = wa.w; a.ba = wa.bias; a.wb = wb.w; a.bb = wb.bias; a.out = out; a.B = B; a.H = H; a.W = W;
+  a.nstrips = (W + F_TW - 1) / F_TW; a.H4 = (H + 3) / 4; a.nseg = a.H4 >= 16 ? 2 : 1;
+  a.nunits = B * a.nstrips * a.nseg;
+  static const hipError_t attr_rc =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv2ab_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM);
+  if (attr_rc != hipSuccess) return attr_rc;
+  int gx = cu_count();
+  if (gx > a.nunits) gx = a.nunits;
+  hipLaunchKernelGGL(conv2ab_fused, dim3(gx), dim3(512), F_SMEM, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace sship

@@ -69,6 +69,10 @@ hipError_t sp_conv1ab_fused(const ConvW& w1b, const _Float16* w1a_frag, const fl
 hipError_t sp_conv3x3_pp(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s);
 bool sp_conv3x3_pp128_fits(int B, int H, int W, int cin);
 hipError_t sp_conv3x3_pp128(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, bool pool, hipStream_t s);
+// conv_fuse2.hip: conv2a -> conv2b -> max-pool in one launch (rolling window over 30-column strips, weights in registers); bit-identical to the
+// two launches of sp_conv3x3_pp.  fits(): the shape is supported and (unless `any_batch`) the batch fills the chip with strip segments
+bool sp_conv2ab_fused_fits(int B, int H, int W, bool any_batch);
+hipError_t sp_conv2ab_fused(const ConvW& wa, const ConvW& wb, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s);
 hipError_t sp_conv1ab_pp(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img, _Float16* out,
                          int B, int H, int W, hipStream_t s);
 // conv_wino.hip: Winograd F(2x2, 3x3) for 64 -> 64 channels (SUPERSLAM_HIP_CONV64=wino)

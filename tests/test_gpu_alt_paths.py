@@ -372,3 +372,25 @@ def test_fused_eigenplaces_stem_agrees_with_the_gemm_stem(tmp_path):
         dmax, cos = float(np.abs(a - b).max()), float(a @ b)
         print("EigenPlaces stem fused vs gemm", k, "max|d|", dmax, "cosine", cos)
         assert np.isfinite(a).all() and dmax <= 1e-3 and cos >= 0.99999, (k, dmax, cos)
+
+
+def test_fused_conv2a_conv2b_is_bit_identical_to_the_two_launches(tmp_path):
+    """csrc/conv_fuse2.hip (round 6): conv2a -> conv2b -> max-pool as one rolling-window kernel whose intermediate map never leaves the CU, against the
+    two conv3x3_pp launches (developer build, SUPERSLAM_HIP_CONV2=fused / split forces either on every batch size).  Same fp16 operands, same k order
+    per accumulator, same rounding points: the pooled conv2b map and the conv3a map behind it are equal BIT FOR BIT.  Sizes: one and several 30-column
+    strips, a partial last strip (widths 164, 160, 620, 125, 75, 48, 32, 688), odd half-resolution widths and heights (62 x 125, 185 x 75: the floor
+    pooling drops the last row / column), strips cut into two row segments and not, heights that are not multiples of the 4-row step, 2-4 images."""
+    outs = {}
+    for mode in ("split", "fused"):
+        out = str(tmp_path / ("conv2_" + mode + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuse2_dump.py"), out], env=_env({"SUPERSLAM_HIP_CONV2": mode}),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(out)
+    assert len(outs["split"].files) >= 16
+    for k in outs["split"].files:
+        a, b = outs["split"][k], outs["fused"][k]
+        nz = int((a != b).sum())
+        print("conv2 fused vs split", k, a.shape, "differing halfs:", nz)
+        assert nz == 0, (k, nz, np.argwhere(a != b)[:8].tolist())
+        assert a.any()
