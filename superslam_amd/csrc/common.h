@@ -32,6 +32,14 @@ inline const char* dev_env(const char* name) { return ::getenv(name); }
 constexpr const char* dev_env(const char*) { return nullptr; }
 #endif
 
+// k order of the 64-input-channel 3x3 convolutions (conv_pp.hip CIN = 64, conv_fuse2.hip).  1 (round 6): (kx, k-step, ky) - the three tap rows of one
+// (kx, k-step) read FOUR input-row fragments for their six (row, ky) pairs instead of six: one LDS fragment read in three is gone.  0: tap-major
+// (ky, kx, k-step), rounds 1-5 (A/B builds: build.py --variant ... -DSSHIP_K_ROWSHARE=0).  Both files must agree: a frame extracted alone (two launches)
+// and the same frame inside a throughput batch (fused kernel) are bit-identical only if every accumulator sees its products in the same order.
+#ifndef SSHIP_K_ROWSHARE
+#define SSHIP_K_ROWSHARE 1
+#endif
+
 // Thread-local last error + status plumbing (host side).
 void set_error(const std::string& msg);
 void log_msg(int level, const char* fmt, ...);

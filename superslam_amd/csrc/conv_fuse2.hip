@@ -153,6 +153,31 @@ __global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
         const float4 b4 = *reinterpret_cast<const float4*>(s_bias + role * 64 + m * 32 + hh * 4 + g * 8);
         acc[n][4 * g + 0] = b4.x; acc[n][4 * g + 1] = b4.y; acc[n][4 * g + 2] = b4.z; acc[n][4 * g + 3] = b4.w;
       }
+    if constexpr (SSHIP_K_ROWSHARE != 0) {
+      // (kx, k-step, ky) order, as conv3x3_pp<64, ...>: group g = 4 kx + ks reads its four row fragments once (ring of 6, fragment r = 4 g + d) for the
+      // six MFMAs of its three tap rows - 2/3 of a ds_read_b128 per MFMA; the A operand of sub-step t = 3 g + ky is register fragment (3 ky + kx) 4 + ks
+      h8_t rbq[6];
+      auto loads_for = [&](int t) __attribute__((always_inline)) {
+        const int g = t / 3, ky = t - 3 * g, kx = g >> 2, ks = g & 3;
+        if (ky == 0) {
+          rbq[(4 * g) % 6] = *reinterpret_cast<const h8_t*>(rb[0] + kx * F_PXB + ks * 32);
+          rbq[(4 * g + 1) % 6] = *reinterpret_cast<const h8_t*>(rb[1] + kx * F_PXB + ks * 32);
+        } else {
+          rbq[(4 * g + ky + 1) % 6] = *reinterpret_cast<const h8_t*>(rb[ky + 1] + kx * F_PXB + ks * 32);
+        }
+      };
+      loads_for(0); loads_for(1);
+#pragma unroll
+      for (int t = 0; t < 36; ++t) {
+        if (t + 2 < 36) loads_for(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const int g = t / 3, ky = t - 3 * g, kx = g >> 2, ks = g & 3;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[n] = mfma32(wreg[((ky * 3 + kx) << 2) + ks], rbq[(4 * g + ky + n) % 6], acc[n]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     constexpr int NBUF = 3;
     h8_t fb[NBUF][2];
     auto load_frags = [&](int idx, int buf) __attribute__((always_inline)) {

@@ -397,6 +397,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp(PpArgs p) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) fb[buf][n] = *reinterpret_cast<const h8_t*>(ib + (n + ky) * P_TWH * 64 + boff[kx][ks]);
     };
+    if constexpr (CIN == 64 && SSHIP_K_ROWSHARE != 0) {
+      // (kx, k-step, ky) order: sub-step t = 3 g + ky of group g = 4 kx + ks multiplies tap row ky; its two N-tiles read input rows ky and ky + 1 of
+      // the wave's four, so a group needs rows 0..3 ONCE (row fragment r = 4 g + d, ring of 6) where the tap-major order read 2 per tap row = 6:
+      // 2 A + 4/3 B fragment reads per 4 MFMAs instead of 2 + 2.  Fragments of sub-step t + 2 are requested before the MFMAs of sub-step t.
+      h8_t ra[3][MT], rbq[6];
+      auto loads_for = [&](int t) __attribute__((always_inline)) {
+        const int g = t / 3, ky = t - 3 * g, kx = g >> 2, ks = g & 3;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ra[t % 3][m] = *reinterpret_cast<const h8_t*>(wc + (((ky * 3 + kx) * 4 + ks) * MT + m) * 512);
+        if (ky == 0) {
+          rbq[(4 * g) % 6] = *reinterpret_cast<const h8_t*>(ib + boff[kx][ks]);
+          rbq[(4 * g + 1) % 6] = *reinterpret_cast<const h8_t*>(ib + P_TWH * 64 + boff[kx][ks]);
+        } else {
+          rbq[(4 * g + ky + 1) % 6] = *reinterpret_cast<const h8_t*>(ib + (ky + 1) * P_TWH * 64 + boff[kx][ks]);
+        }
+      };
+      loads_for(0); loads_for(1);
+      if constexpr (chunk == 0 && !SSHIP_PP_ACC_PRELOAD) acc_init();
+#pragma unroll
+      for (int t = 0; t < 36; ++t) {
+        if (t + 2 < 36 && !(SSHIP_PP_ABL & 1)) loads_for(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const int g = t / 3, ky = t - 3 * g;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            if constexpr ((SSHIP_PP_ABL & 2) != 0) asm volatile("" :: "v"(ra[t % 3][m]), "v"(rbq[(4 * g + ky + n) % 6]));
+            else acc[m][n] = mfma32(ra[t % 3][m], rbq[(4 * g + ky + n) % 6], acc[m][n]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) load_frags(i, i);
     if constexpr (chunk == 0 && !SSHIP_PP_ACC_PRELOAD) acc_init();
