@@ -675,16 +675,17 @@ static hipError_t conv3(const ConvW& w, const _Float16* in, _Float16* out, int B
   return sp_conv3x3_pp(w, in, out, B, H, W, pool, s);
 #endif
 }
-// conv2a + conv2b + pool as one launch (conv_fuse2.hip) when the batch fills the chip with strip segments; the developer build's
-// SUPERSLAM_HIP_CONV2 = split / fused forces either path (A/B, and the fused kernel on small frames in tests/test_gpu_alt_paths.py)
+// conv2a + conv2b + pool run as ONE launch (conv_fuse2.hip) at every batch size - the strips are cut into as many row segments as it takes to give
+// every CU work, so a one-pair call gains as well (0.736 -> 0.710 ms) - unless the shape does not fit the kernel (maps under 8 pixels, images beyond
+// 32-bit offsets): then, and in the developer build under SUPERSLAM_HIP_CONV2=split (A/B; tests/test_gpu_alt_paths.py), the two conv3x3_pp launches run.
+// Both paths give the same bits.  (sship_sp_debug_activation layer 2 = conv2a's map exists only on the two-launch path.)
 static bool conv2_fused(int B, int H2, int W2) {
 #if SSHIP_DEV_SWITCHES
   static const std::string mode = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV2"); return std::string(e ? e : ""); }();
   static const bool other = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV64"); return e != nullptr; }();
   if (mode == "split" || other || conv_mode() != 1) return false;
-  if (mode == "fused") return sp_conv2ab_fused_fits(B, H2, W2, true);
 #endif
-  return sp_conv2ab_fused_fits(B, H2, W2, false);
+  return sp_conv2ab_fused_fits(B, H2, W2, true);
 }
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s);
 static bool desc_dense_mode() {
@@ -716,7 +717,7 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
   SSHIP_HIP_CHECK(conv1ab(sp, imgs, sp->a1b.as<_Float16>(), B, H, W, s));
   g_timer.mark_fine("sp_gpu_infer:encoder/conv1a+conv1b+pool", s);
   if (conv2_fused(B, H2, W2)) {
-    // throughput batches: conv2a -> conv2b -> pool in one launch, the map between them never leaves the CU (conv_fuse2.hip; bit-identical)
+    // conv2a -> conv2b -> pool in one launch, the map between them never leaves the CU (conv_fuse2.hip; bit-identical to the two launches below)
     SSHIP_HIP_CHECK(sp_conv2ab_fused(sp->c2a, sp->c2b, sp->a1b.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, s));
     g_timer.mark_fine("sp_gpu_infer:encoder/conv2a+conv2b+pool", s);
   } else {

@@ -20,9 +20,11 @@
 //     VGPR base plus an immediate) in 5 120 B = 5 DMA instructions; out-of-image pixels get their voffset pushed out of the buffer's range and the DMA
 //     writes zeros (scripts/ubench/lds_dma_oob.hip).  conv2b's zero padding is on conv2a's OUTPUT: the producers write zeros for intermediate pixels
 //     outside the image.
-//   * same fp16 operands, same k order per accumulator (tap-major, four k-steps per tap, accumulator started from the bias), same rounding points as
-//     conv3x3_pp<64, 64, ...>: the output is BIT-IDENTICAL to the two-launch path (tests/test_gpu_alt_paths.py, tests/test_gpu_bench_batch_parity.py),
-//     which the library keeps for batches too small to fill the chip with strips.
+//   * same fp16 operands, same k order per accumulator ((kx, k-step, ky), accumulator started from the bias: common.h SSHIP_K_ROWSHARE), same rounding points as
+//     conv3x3_pp<64, 64, ...>: the output is BIT-IDENTICAL to the two-launch path (tests/test_gpu_alt_paths.py), which the library keeps for shapes
+//     the kernel does not take and the developer build for A/B runs.
+//   * a strip is cut into row segments (2 conv2a rows recomputed and a 2-slot pipeline fill per segment) until there are ~2 units per CU: a one-pair call
+//     (46 strips) runs 506 segments of 4-5 steps - 0.736 -> 0.710 ms per pair; 128 images run 2 segments per strip = 23 units per CU.
 // LDS: 2 x 12 x 5 120 B rings + 512 B bias = 123.4 KB, one workgroup per CU.
 #include "common.h"
 #include "kernels.h"
@@ -282,20 +284,35 @@ __global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
   if (pending) epi_consumer();
 }
 
+// row segments per strip: enough units for ~2 per CU (a pair of frames is 46 strips: cut into 11 segments of 4-5 steps it is 506 units), at least 4
+// steps per segment (every segment recomputes 2 conv2a rows and fills a 2-slot pipeline), at least 2 for tall maps (23 units per CU at 128 images).
+// A function of the shape only - and segmentation never changes the arithmetic: every split gives the same bits.
+static int f2_nseg(int B, int nstrips, int H4) {
+#if SSHIP_DEV_SWITCHES
+  static const int forced = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV2_NSEG"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return forced > H4 ? H4 : forced;
+#endif
+  const long base = (long)B * nstrips;
+  int want = (int)((2l * cu_count() + base - 1) / base);
+  const int lo = H4 >= 16 ? 2 : 1, hi = H4 / 4 > 1 ? H4 / 4 : 1;
+  if (want < lo) want = lo;
+  if (want > hi) want = hi;
+  return want;
+}
 bool sp_conv2ab_fused_fits(int B, int H, int W, bool any_batch) {
   if (H < 8 || W < 8 || B < 1) return false;
   if ((size_t)H * W * 128 >= 0x7f000000ull) return false;  // offsets inside one image are 32-bit
   const int nstrips = (W + F_TW - 1) / F_TW, H4 = (H + 3) / 4;
-  const int nseg = H4 >= 16 ? 2 : 1;
-  // throughput batches only: every CU gets several strip segments (a pair of frames is 92 segments on 256 CUs: the two-launch path is faster there)
-  return any_batch || (long long)B * nstrips * nseg >= 4ll * cu_count();
+  // any_batch = false: only batches that give every CU several strip segments without cutting the strips further (round 6's first rule; the library
+  // now fuses at every batch size - f2_nseg cuts the strips into as many row segments as it takes - and asks with any_batch = true)
+  return any_batch || (long long)B * nstrips * (H4 >= 16 ? 2 : 1) >= 4ll * cu_count();
 }
 
 hipError_t sp_conv2ab_fused(const ConvW& wa, const ConvW& wb, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s) {
   if (wa.cin != 64 || wa.cout != 64 || wa.ct != 64 || wb.cin != 64 || wb.cout != 64 || wb.ct != 64) return hipErrorInvalidValue;
   F2Args a{};
   a.in = in; a.wa = wa.w; a.ba = wa.bias; a.wb = wb.w; a.bb = wb.bias; a.out = out; a.B = B; a.H = H; a.W = W;
-  a.nstrips = (W + F_TW - 1) / F_TW; a.H4 = (H + 3) / 4; a.nseg = a.H4 >= 16 ? 2 : 1;
+  a.nstrips = (W + F_TW - 1) / F_TW; a.H4 = (H + 3) / 4; a.nseg = f2_nseg(B, a.nstrips, a.H4);
   a.nunits = B * a.nstrips * a.nseg;
   static const hipError_t attr_rc =
       hipFuncSetAttribute(reinterpret_cast<const void*>(conv2ab_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM);
