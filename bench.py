@@ -762,8 +762,14 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
             w = poller.window(ta, tb, settle_s=0.25 * (tb - ta))
             if not w:
                 return None
-            return {"joules_per_launch": round(w["avg_W"] * ms * 1e-3, 5), "avg_W": w["avg_W"], "sclk_MHz": w["sclk_MHz"],
-                    "launch_ms_energy_loop": round(ms, 4), "samples": w["n"]}
+            e = {"joules_per_launch": round(w["avg_W"] * ms * 1e-3, 5), "avg_W": w["avg_W"], "sclk_MHz": w["sclk_MHz"],
+                 "launch_ms_energy_loop": round(ms, 4), "samples": w["n"]}
+            # the MEASURED bound next to the FLOP/B classification (`bound`): a stage that loops at >= 97 % of the board's cap is power-bound - its
+            # launch time is its joules divided by the cap, whatever the two datasheet roofs say
+            if poller.cap_w:
+                e["bound_measured"] = ("power cap (time = joules / cap)" if w["avg_W"] >= 0.97 * poller.cap_w
+                                       else f"below the cap ({w['avg_W'] / poller.cap_w:.2f} of it): latency / memory / issue bound")
+            return e
 
         sp_ids = sp_layer_ids
         lg_ids = {name: sid for sid, name in enumerate(lg_flops)}

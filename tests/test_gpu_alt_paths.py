@@ -381,16 +381,21 @@ def test_fused_conv2a_conv2b_is_bit_identical_to_the_two_launches(tmp_path):
     strips, a partial last strip (widths 164, 160, 620, 125, 75, 48, 32, 688), odd half-resolution widths and heights (62 x 125, 185 x 75: the floor
     pooling drops the last row / column), strips cut into two row segments and not, heights that are not multiples of the 4-row step, 2-4 images."""
     outs = {}
-    for mode in ("split", "fused"):
+    # "fused" cuts every strip into the row segments the library picks for the batch (conv_fuse2.hip: f2_nseg); the two forced segment counts prove
+    # that the cut never changes the arithmetic: one segment per strip (the longest pipelines) and seven (segments of 2-7 steps, many seams)
+    for mode, env in (("split", {"SUPERSLAM_HIP_CONV2": "split"}), ("fused", {"SUPERSLAM_HIP_CONV2": "fused"}),
+                      ("fused_nseg1", {"SUPERSLAM_HIP_CONV2": "fused", "SUPERSLAM_HIP_CONV2_NSEG": "1"}),
+                      ("fused_nseg7", {"SUPERSLAM_HIP_CONV2": "fused", "SUPERSLAM_HIP_CONV2_NSEG": "7"})):
         out = str(tmp_path / ("conv2_" + mode + ".npz"))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuse2_dump.py"), out], env=_env({"SUPERSLAM_HIP_CONV2": mode}),
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuse2_dump.py"), out], env=_env(env),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[mode] = np.load(out)
     assert len(outs["split"].files) >= 16
-    for k in outs["split"].files:
-        a, b = outs["split"][k], outs["fused"][k]
-        nz = int((a != b).sum())
-        print("conv2 fused vs split", k, a.shape, "differing halfs:", nz)
-        assert nz == 0, (k, nz, np.argwhere(a != b)[:8].tolist())
-        assert a.any()
+    for mode in ("fused", "fused_nseg1", "fused_nseg7"):
+        for k in outs["split"].files:
+            a, b = outs["split"][k], outs[mode][k]
+            nz = int((a != b).sum())
+            print("conv2", mode, "vs split", k, a.shape, "differing halfs:", nz)
+            assert nz == 0, (mode, k, nz, np.argwhere(a != b)[:8].tolist())
+            assert a.any()
