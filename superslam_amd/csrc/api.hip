@@ -687,6 +687,16 @@ static bool conv2_fused(int B, int H2, int W2) {
 #endif
   return sp_conv2ab_fused_fits(B, H2, W2, true);
 }
+// conv3a (64 -> 128) runs on conv3x3_pp<64, 64> (two cout tiles).  The rolling-window kernel's one-layer form (conv_fuse2.hip: conv_roll<true>, all 128
+// output channels in one launch, weights in registers) is bit-identical and draws the SAME joules (0.7276 vs 0.7274 J per 128-image launch,
+// profiles/r06_l_*): it exists in the developer build only (SUPERSLAM_HIP_CONV3A=roll; A/B in tests/test_gpu_alt_paths.py).
+static hipError_t conv3a_layer(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s) {
+#if SSHIP_DEV_SWITCHES
+  static const bool roll = [] { const char* e = dev_env("SUPERSLAM_HIP_CONV3A"); return e && std::string(e) == "roll"; }();
+  if (roll && conv_mode() == 1 && w.cin == 64 && w.cout == 128 && w.ct == 64 && sp_conv3a_roll_fits(B, H, W)) return sp_conv3a_roll(w, in, out, B, H, W, s);
+#endif
+  return conv3(w, in, out, B, H, W, false, s);
+}
 static hipError_t conv1ab(sship_sp* sp, const uint8_t* img, _Float16* out, int B, int H, int W, hipStream_t s);
 static bool desc_dense_mode() {
   static const bool v = [] { const char* e = dev_env("SUPERSLAM_HIP_DESC"); return e && std::string(e) == "dense"; }();
@@ -726,7 +736,7 @@ static int sp_network(sship_sp* sp, const uint8_t* imgs, int B, int H, int W, hi
     SSHIP_HIP_CHECK(conv3(sp->c2b, sp->a2a.as<_Float16>(), sp->a2b.as<_Float16>(), B, H2, W2, true, s));
     g_timer.mark_fine("sp_gpu_infer:encoder/conv2b+pool", s);
   }
-  SSHIP_HIP_CHECK(conv3(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, false, s));
+  SSHIP_HIP_CHECK(conv3a_layer(sp->c3a, sp->a2b.as<_Float16>(), sp->a3a.as<_Float16>(), B, H4, W4, s));
   g_timer.mark_fine("sp_gpu_infer:encoder/conv3a", s);
   SSHIP_HIP_CHECK(conv3(sp->c3b, sp->a3a.as<_Float16>(), sp->a3b.as<_Float16>(), B, H4, W4, true, s));
   g_timer.mark_fine("sp_gpu_infer:encoder/conv3b+pool", s);
@@ -981,7 +991,7 @@ extern "C" int sship_sp_bench_layer(sship_sp* sp, int layer, int batch, int h, i
         return sp_conv2ab_fused(sp->c2a, sp->c2b, a1b, a2b, batch, H2, W2, s);
       case 2: return conv3(sp->c2a, a1b, a2a, batch, H2, W2, false, s);
       case 3: return conv3(sp->c2b, a2a, a2b, batch, H2, W2, true, s);
-      case 4: return conv3(sp->c3a, a2b, a3a, batch, H4, W4, false, s);
+      case 4: return conv3a_layer(sp->c3a, a2b, a3a, batch, H4, W4, s);
       case 5: return conv3(sp->c3b, a3a, a3b, batch, H4, W4, true, s);
       case 6: return conv3(sp->c4a, a3b, a4a, batch, Hc, Wc, false, s);
       case 7: return conv3(sp->c4b, a4a, a4b, batch, Hc, Wc, false, s);

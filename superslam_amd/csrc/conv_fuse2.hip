@@ -53,21 +53,29 @@ constexpr size_t F_SMEM = 2 * F_RINGB + 2 * 64 * 4;
 
 struct F2Walk { int u, k, S, b, s, r0; };  // wave-uniform: unit, step inside the unit (0 .. S), steps of the unit, image, strip, first row
 
-__global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
+// SINGLE = false: the fused pair above (kernel name conv2ab_fused).  SINGLE = true (conv3a_roll): ONE 64 -> 128 layer (conv3a) on the same machinery -
+// all 8 waves are "producers" (wave = M-tile m of 4 x row pair rp of 2) that read the INPUT ring and store their rows to global memory; strips are
+// 32 columns wide (nothing is recomputed: there is no second layer), the halo is one pixel.  Against conv3x3_pp<64, 64> with its two cout tiles: the
+// input is fetched once instead of twice, the weights come from registers instead of LDS, and the row pair 1 waves write their rows at the START of
+// their next slot, under the row pair 0 waves' MFMAs.  Same k order, same rounding points: bit-identical - and the same joules (profiles/r06_l_*), so only
+// the developer build instantiates it (A/B).
+template <bool SINGLE>
+__global__ __launch_bounds__(512, 2) void conv_roll(F2Args p) {
+  constexpr int TW = SINGLE ? 32 : F_TW, HALO = SINGLE ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char f2_smem[];
   char* s_in = f2_smem;
   char* s_mid = f2_smem + F_RINGB;
-  float* s_bias = reinterpret_cast<float*>(f2_smem + 2 * F_RINGB);  // [role][64]
+  float* s_bias = reinterpret_cast<float*>(f2_smem + 2 * F_RINGB);  // [role][64] (SINGLE: [128])
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 2, gw = wave & 3, m = gw & 1, rp = gw >> 1;
+  const int role = SINGLE ? 0 : wave >> 2, gw = wave & 3, m = SINGLE ? gw : gw & 1, rp = SINGLE ? wave >> 2 : gw >> 1;
   const int Ho = p.H >> 1, Wo = p.W >> 1;
 
-  if (tid < 128) s_bias[tid] = tid < 64 ? p.ba[tid] : p.bb[tid - 64];
+  if (tid < 128) s_bias[tid] = (SINGLE || tid < 64) ? p.ba[tid] : p.bb[tid - 64];
   // this wave's 36 A fragments (M-tile m of its layer), for the whole launch
   h8_t wreg[36];
   {
-    const _Float16* w = (role ? p.wb : p.wa) + m * 512 + lane * 8;
+    const _Float16* w = (SINGLE ? p.wa + (m >> 1) * 36864 + (m & 1) * 512 : (role ? p.wb : p.wa) + m * 512) + lane * 8;  // SINGLE: cout tile m >> 1 of the ct = 64 packing
 #pragma unroll
     for (int idx = 0; idx < 36; ++idx) wreg[idx] = *reinterpret_cast<const h8_t*>(w + idx * 1024);
   }
@@ -109,19 +117,19 @@ __global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
   typedef int rsrc4_t __attribute__((ext_vector_type(4)));
   auto dma_step = [&](const F2Walk& w, int q3) __attribute__((always_inline)) {
     // buffer of image b, based two rows and two pixels before it: offsets stay non-negative and 32-bit
-    const unsigned long long ba = (unsigned long long)(uintptr_t)p.in + ((unsigned long long)w.b * p.H * p.W - (unsigned long long)(2 * p.W + 2)) * 128ull;
+    const unsigned long long ba = (unsigned long long)(uintptr_t)p.in + ((unsigned long long)w.b * p.H * p.W - (unsigned long long)(HALO * p.W + HALO)) * 128ull;
     rsrc4_t rs;
     rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ba);
     rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba >> 32) & 0xffffu));
     rs[2] = 0x7ffffff0;
     rs[3] = 0x00020000;
-    const int row0 = w.r0 + 4 * w.k;  // image row of i = 0 is row0 - 2
-    const unsigned soff = (unsigned)((row0 * p.W + F_TW * w.s) * 128);
-    const int pxlo = w.s == 0 ? 2 : 0, pxhi = min(34, p.W - F_TW * w.s + 2);  // ring pixel px is image column 30 s - 2 + px
+    const int row0 = w.r0 + 4 * w.k;  // image row of i = 0 is row0 - HALO
+    const unsigned soff = (unsigned)((row0 * p.W + TW * w.s) * 128);
+    const int pxlo = w.s == 0 ? HALO : 0, pxhi = min(34, p.W - TW * w.s + HALO);  // ring pixel px is image column TW s - HALO + px
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
       if (e >= n_dma) break;
-      const int ri = row0 - 2 + d_i[e];
+      const int ri = row0 - HALO + d_i[e];
       const bool rowok = ri >= 0 && ri < p.H;
       const unsigned v = (rowok && d_px[e] >= pxlo && d_px[e] < pxhi) ? d_voff[e] : F_OOB;
       int rr = 4 * q3 + d_i[e];
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + role * 64 + m * 32 + hh * 4 + g * 8);
+        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + (SINGLE ? 0 : role * 64) + m * 32 + hh * 4 + g * 8);
         acc[n][4 * g + 0] = b4.x; acc[n][4 * g + 1] = b4.y; acc[n][4 * g + 2] = b4.z; acc[n][4 * g + 3] = b4.w;
       }
     if constexpr (SSHIP_K_ROWSHARE != 0) {
@@ -248,6 +256,32 @@ __global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
     }
   };
 
+  // SINGLE: ReLU -> fp16 -> this wave's two output rows (image rows r0 + 4k + 2 rp + n, column 32 s + j, channels 32 m + 8 (g + hh) .. + 7), 16-byte stores
+  bool pend_ok1 = false;
+  auto prep_single = [&](const F2Walk& w) __attribute__((always_inline)) {
+    const int ro = w.r0 + 4 * w.k + 2 * rp, col = TW * w.s + j;
+    pend_ok = col < p.W && ro < p.H;
+    pend_ok1 = col < p.W && ro + 1 < p.H;
+    pend_pix = p.out + ((size_t)(w.b * p.H + ro) * p.W + col) * 128 + m * 32 + hh * 8;
+  };
+  auto epi_single = [&]() __attribute__((always_inline)) {
+    const h2_t z2 = {(_Float16)0.f, (_Float16)0.f};
+    auto relu2 = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
+      h2_t v = {(_Float16)lo, (_Float16)hi};
+      v = __builtin_elementwise_max(v, z2);
+      return *reinterpret_cast<const unsigned*>(&v);
+    };
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const f16x_t& a = acc[n];
+        const auto r0 = __builtin_amdgcn_permlane32_swap(relu2(a[4 * g + 0], a[4 * g + 1]), relu2(a[4 * g + 4], a[4 * g + 5]), false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(relu2(a[4 * g + 2], a[4 * g + 3]), relu2(a[4 * g + 6], a[4 * g + 7]), false, false);
+        if (n ? pend_ok1 : pend_ok) *reinterpret_cast<uint4*>(pend_pix + (size_t)n * p.W * 128 + g * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+  };
+
   // ---------------- schedule: slot t = DMA of load step t + 2 | producer step t | consumer step t - 2, one barrier ----------------
   F2Walk wd, wr;
   wd.u = u_begin; decode(wd);
@@ -258,22 +292,28 @@ __global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
   qd3 = 2;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int lag = role ? 2 : 0;
+  const int lag = (!SINGLE && role) ? 2 : 0;
   int q3 = 0;  // (this role's step index) % 3
   bool pending = false;  // consumers: the previous step's accumulators wait for their epilogue
 #pragma unroll 1
-  for (int t = 0; t < Q + 2; ++t) {
+  for (int t = 0; t < Q + (SINGLE ? 0 : 2); ++t) {
     if (wd.u < u_end) { dma_step(wd, qd3); advance(wd); }
     qd3 = qd3 == 2 ? 0 : qd3 + 1;
-    if (pending) { epi_consumer(); pending = false; }
+    if (pending) { if constexpr (SINGLE) epi_single(); else epi_consumer(); pending = false; }
     const int q = t - lag;
     if (q >= 0 && q < Q) {
-      // producers: the last step of a unit (k = S) only makes rows r1 - 1, r1 (row pair 0); consumers: it is empty
-      const bool active = role == 0 ? (wr.k < wr.S || rp == 0) : wr.k < wr.S;
+      // producers: the last step of a unit (k = S) only makes rows r1 - 1, r1 (row pair 0); consumers (and SINGLE, whose k = S step only exists for
+      // its load of the halo row below the segment): it is empty
+      const bool active = (!SINGLE && role == 0) ? (wr.k < wr.S || rp == 0) : wr.k < wr.S;
       if (active) {
         mfma_step(q3);
-        if (role == 0) epi_producer(wr, q3);
-        else { prep_consumer(wr); pending = true; }
+        if constexpr (SINGLE) {
+          prep_single(wr);
+          if (rp == 0) epi_single(); else pending = true;  // row pair 1 stores under row pair 0's next MFMA loop
+        } else {
+          if (role == 0) epi_producer(wr, q3);
+          else { prep_consumer(wr); pending = true; }
+        }
       }
       advance(wr);
       q3 = q3 == 2 ? 0 : q3 + 1;
@@ -281,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void conv2ab_fused(F2Args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (pending) epi_consumer();
+  if (pending) { if constexpr (SINGLE) epi_single(); else epi_consumer(); }
 }
 
 // row segments per strip: enough units for ~2 per CU (a pair of frames is 46 strips: cut into 11 segments of 4-5 steps it is 506 units), at least 4
@@ -315,12 +355,35 @@ hipError_t sp_conv2ab_fused(const ConvW& wa, const ConvW& wb, const _Float16* in
   a.nstrips = (W + F_TW - 1) / F_TW; a.H4 = (H + 3) / 4; a.nseg = f2_nseg(B, a.nstrips, a.H4);
   a.nunits = B * a.nstrips * a.nseg;
   static const hipError_t attr_rc =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv2ab_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_roll<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM);
   if (attr_rc != hipSuccess) return attr_rc;
   int gx = cu_count();
   if (gx > a.nunits) gx = a.nunits;
-  hipLaunchKernelGGL(conv2ab_fused, dim3(gx), dim3(512), F_SMEM, s, a);
+  hipLaunchKernelGGL(conv_roll<false>, dim3(gx), dim3(512), F_SMEM, s, a);
   return hipGetLastError();
 }
+
+#if SSHIP_DEV_SWITCHES
+// conv3a (64 -> 128, no pool) on the rolling-window kernel: one launch computes all 128 output channels (conv3x3_pp<64, 64> needs two cout tiles,
+// i.e. stages the input twice).  Bit-identical to it - and no cheaper: 0.7274 against 0.7276 J per 128-image launch, 521 us both (profiles/r06_l_*):
+// conv3a's joules are its MFMAs and its 1.06 GB of output stores, which this form does not change.  Developer build only (SUPERSLAM_HIP_CONV3A=roll).
+bool sp_conv3a_roll_fits(int B, int H, int W) {
+  return H >= 8 && W >= 8 && B >= 1 && (size_t)H * W * 128 < 0x7f000000ull;  // input offsets inside one image are 32-bit (the output is addressed by pointers)
+}
+hipError_t sp_conv3a_roll(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s) {
+  if (w.cin != 64 || w.cout != 128 || w.ct != 64) return hipErrorInvalidValue;
+  F2Args a{};
+  a.in = in; a.wa = w.w; a.ba = w.bias; a.wb = w.w; a.bb = w.bias; a.out = out; a.B = B; a.H = H; a.W = W;
+  a.nstrips = (W + 31) / 32; a.H4 = (H + 3) / 4; a.nseg = f2_nseg(B, a.nstrips, a.H4);
+  a.nunits = B * a.nstrips * a.nseg;
+  static const hipError_t attr_rc =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_roll<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM);
+  if (attr_rc != hipSuccess) return attr_rc;
+  int gx = cu_count();
+  if (gx > a.nunits) gx = a.nunits;
+  hipLaunchKernelGGL(conv_roll<true>, dim3(gx), dim3(512), F_SMEM, s, a);
+  return hipGetLastError();
+}
+#endif
 
 }  // namespace sship

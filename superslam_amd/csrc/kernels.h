@@ -73,6 +73,9 @@ hipError_t sp_conv3x3_pp128(const ConvW& w, const _Float16* in, _Float16* out, i
 // two launches of sp_conv3x3_pp.  fits(): the shape is supported and (unless `any_batch`) the batch fills the chip with strip segments
 bool sp_conv2ab_fused_fits(int B, int H, int W, bool any_batch);
 hipError_t sp_conv2ab_fused(const ConvW& wa, const ConvW& wb, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s);
+// the same rolling-window kernel as ONE 64 -> 128 layer (conv3a): all 128 output channels in one launch, weights in registers; bit-identical to sp_conv3x3_pp
+bool sp_conv3a_roll_fits(int B, int H, int W);
+hipError_t sp_conv3a_roll(const ConvW& w, const _Float16* in, _Float16* out, int B, int H, int W, hipStream_t s);
 hipError_t sp_conv1ab_pp(const ConvW& w1b, const _Float16* w1a_frag, const float* b1a, const uint8_t* img, _Float16* out,
                          int B, int H, int W, hipStream_t s);
 // conv_wino.hip: Winograd F(2x2, 3x3) for 64 -> 64 channels (SUPERSLAM_HIP_CONV64=wino)

@@ -377,13 +377,15 @@ def test_fused_eigenplaces_stem_agrees_with_the_gemm_stem(tmp_path):
 def test_fused_conv2a_conv2b_is_bit_identical_to_the_two_launches(tmp_path):
     """csrc/conv_fuse2.hip (round 6): conv2a -> conv2b -> max-pool as one rolling-window kernel whose intermediate map never leaves the CU, against the
     two conv3x3_pp launches (developer build, SUPERSLAM_HIP_CONV2=fused / split forces either on every batch size).  Same fp16 operands, same k order
-    per accumulator, same rounding points: the pooled conv2b map and the conv3a map behind it are equal BIT FOR BIT.  Sizes: one and several 30-column
+    per accumulator, same rounding points: the pooled conv2b map and the conv3a map behind it are equal BIT FOR BIT.  The conv3a map is also the A/B of
+    the kernel's one-layer form (conv_roll<true>: conv3a's 128 output channels in one launch) against conv3x3_pp<64, 64> with its two cout tiles, which
+    the library runs; the "fused" mode selects the one-layer form with SUPERSLAM_HIP_CONV3A=roll (measured at the same joules, so not shipped).  Sizes: one and several 30-column
     strips, a partial last strip (widths 164, 160, 620, 125, 75, 48, 32, 688), odd half-resolution widths and heights (62 x 125, 185 x 75: the floor
     pooling drops the last row / column), strips cut into two row segments and not, heights that are not multiples of the 4-row step, 2-4 images."""
     outs = {}
     # "fused" cuts every strip into the row segments the library picks for the batch (conv_fuse2.hip: f2_nseg); the two forced segment counts prove
     # that the cut never changes the arithmetic: one segment per strip (the longest pipelines) and seven (segments of 2-7 steps, many seams)
-    for mode, env in (("split", {"SUPERSLAM_HIP_CONV2": "split"}), ("fused", {"SUPERSLAM_HIP_CONV2": "fused"}),
+    for mode, env in (("split", {"SUPERSLAM_HIP_CONV2": "split"}), ("fused", {"SUPERSLAM_HIP_CONV2": "fused", "SUPERSLAM_HIP_CONV3A": "roll"}),
                       ("fused_nseg1", {"SUPERSLAM_HIP_CONV2": "fused", "SUPERSLAM_HIP_CONV2_NSEG": "1"}),
                       ("fused_nseg7", {"SUPERSLAM_HIP_CONV2": "fused", "SUPERSLAM_HIP_CONV2_NSEG": "7"})):
         out = str(tmp_path / ("conv2_" + mode + ".npz"))
