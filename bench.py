@@ -764,11 +764,11 @@ def extras(out, args, torch, np, L, sp, lg, fe, chunks, base, stream, wdir, worl
                 return None
             e = {"joules_per_launch": round(w["avg_W"] * ms * 1e-3, 5), "avg_W": w["avg_W"], "sclk_MHz": w["sclk_MHz"],
                  "launch_ms_energy_loop": round(ms, 4), "samples": w["n"]}
-            # the MEASURED bound next to the FLOP/B classification (`bound`): a stage that loops at >= 95 % of the board's cap (the SMU holds the
-            # average a few per cent under the limit while it throttles the clock: conv1a+1b reads 1 355-1 385 W at 1.9 of 2.4 GHz) is power-bound -
+            # the MEASURED bound next to the FLOP/B classification (`bound`): a stage that loops at >= 93 % of the board's cap (the SMU holds the
+            # average a few per cent under the limit while it throttles the clock: conv1a+1b reads 1 330-1 385 W at 1.9 of 2.4 GHz) is power-bound -
             # its launch time is its joules divided by the cap, whatever the two datasheet roofs say
             if poller.cap_w:
-                e["bound_measured"] = ("power cap (time = joules / cap)" if w["avg_W"] >= 0.95 * poller.cap_w
+                e["bound_measured"] = ("power cap (time = joules / cap)" if w["avg_W"] >= 0.93 * poller.cap_w
                                        else f"below the cap ({w['avg_W'] / poller.cap_w:.2f} of it): latency / memory / issue bound")
             return e
 
