@@ -12,7 +12,7 @@ from superslam_amd.synth import make_frame
 from superslam_amd.weights import make_superpoint_weights, save_safetensors
 
 out = sys.argv[1]
-sizes = sys.argv[2:] or ["200x328x2", "240x320x2", "376x1241x2", "96x250x4", "370x150x2", "64x96x2", "72x64x3", "376x1376x4"]
+sizes = sys.argv[2:] or ["200x328x2", "240x320x2", "376x1241x2", "96x250x4", "370x150x2", "64x96x2", "72x64x3", "376x1376x4", "1080x1920x2", "32x40x5"]
 torch.cuda.set_device(0); _lib.init(0)
 d = tempfile.mkdtemp(); save_safetensors(make_superpoint_weights(0), d + "/sp.safetensors")
 res = {}

@@ -380,7 +380,7 @@ def test_fused_conv2a_conv2b_is_bit_identical_to_the_two_launches(tmp_path):
     per accumulator, same rounding points: the pooled conv2b map and the conv3a map behind it are equal BIT FOR BIT.  The conv3a map is also the A/B of
     the kernel's one-layer form (conv_roll<true>: conv3a's 128 output channels in one launch) against conv3x3_pp<64, 64> with its two cout tiles, which
     the library runs; the "fused" mode selects the one-layer form with SUPERSLAM_HIP_CONV3A=roll (measured at the same joules, so not shipped).  Sizes: one and several 30-column
-    strips, a partial last strip (widths 164, 160, 620, 125, 75, 48, 32, 688), odd half-resolution widths and heights (62 x 125, 185 x 75: the floor
+    strips, a partial last strip (widths 164, 160, 620, 125, 75, 48, 32, 688, 960, 20), the engine's maximum frame (1080 x 1920) and a 32 x 40 one, odd half-resolution widths and heights (62 x 125, 185 x 75: the floor
     pooling drops the last row / column), strips cut into two row segments and not, heights that are not multiples of the 4-row step, 2-4 images."""
     outs = {}
     # "fused" cuts every strip into the row segments the library picks for the batch (conv_fuse2.hip: f2_nseg); the two forced segment counts prove
