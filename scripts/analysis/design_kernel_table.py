@@ -12,7 +12,7 @@ P = b["config"]["pairs_per_call"]
 ROWS = [  # (bench key, table name, work per pair, one-line design)
     ("conv1a+conv1b+pool", "`conv3x3_pp<64,64,pool,fuse1a>` conv1a + conv1b + pool — **dominant** (`conv_pp.hip`)", "77.5 GFLOP (36 %); 1.03 MB u8 in, 33.1 MB out",
      "persistent workgroup per CU, conv1b weights resident in LDS, two 4-wave role groups ping-pong MFMA half-steps against staging / epilogue; conv1a evaluated with MFMAs (K = 9 → 16) straight from u8 dwords into the LDS tile: the full-resolution 64-channel map never exists in HBM; round 6: (kx, k-step, ky) order - the tap rows of a (kx, k-step) share their input-row fragments (−17 % LDS fragment reads, −2.4 % joules)"),
-    ("conv2a+conv2b+pool", "`conv2ab_fused` conv2a → conv2b → pool, ONE launch (`conv_fuse2.hip`, round 6)", "19.1 GFLOP; 33.1 MB in + 8.3 MB out (the 33.1 MB map between the layers never leaves the CU)",
+    ("conv2a+conv2b+pool", "`conv_roll<false>` conv2a → conv2b → pool, ONE launch (`conv_fuse2.hip`, round 6)", "19.1 GFLOP; 33.1 MB in + 8.3 MB out (the 33.1 MB map between the layers never leaves the CU)",
      "rolling window down 30-column strips (only the horizontal halo is recomputed: 32/30), 4 producer waves (conv2a) + 4 consumer waves (conv2b) per workgroup, each wave's M-tile of weights in REGISTERS (36 A fragments = 144 VGPRs), two 12-row LDS rings, input rows by `buffer_load … lds`, the two roles' epilogues skewed half a slot so each rides under the other's MFMAs; bit-identical to the two `conv3x3_pp` launches a one-pair call still runs"),
     ("conv3a", "`conv3x3_pp<64,64>` conv3a 64 → 128 (`conv_pp.hip`)", "4.8 GFLOP; 8.3 + 16.6 MB", "the ping-pong kernel without the conv1a stage, two cout tiles; staging addresses affine, out-of-image halo by the buffer range check; tiles walked down the columns (halo rows are L2 hits)"),
     ("conv3b+pool", "`conv3x3_pp128w<pool>` conv3b (`conv_pp128.hip`)", "9.5 GFLOP; 16.6 + 4.1 MB", "16×32-pixel tiles, input chunk global → LDS by `buffer_load … lds` (swizzle on the source address, zeros from the range check), weight ring by LDS-DMA, 0.5 `ds_read_b128` per MFMA (tap rows share row fragments)"),

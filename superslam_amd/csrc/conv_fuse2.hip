@@ -53,7 +53,7 @@ constexpr size_t F_SMEM = 2 * F_RINGB + 2 * 64 * 4;
 
 struct F2Walk { int u, k, S, b, s, r0; };  // wave-uniform: unit, step inside the unit (0 .. S), steps of the unit, image, strip, first row
 
-// SINGLE = false: the fused pair above (kernel name conv2ab_fused).  SINGLE = true (conv3a_roll): ONE 64 -> 128 layer (conv3a) on the same machinery -
+// SINGLE = false: the fused pair above (rocprofv3 shows it as conv_roll<false>; the kernel was named conv2ab_fused before it became a template).  SINGLE = true (conv3a_roll): ONE 64 -> 128 layer (conv3a) on the same machinery -
 // all 8 waves are "producers" (wave = M-tile m of 4 x row pair rp of 2) that read the INPUT ring and store their rows to global memory; strips are
 // 32 columns wide (nothing is recomputed: there is no second layer), the halo is one pixel.  Against conv3x3_pp<64, 64> with its two cout tiles: the
 // input is fetched once instead of twice, the weights come from registers instead of LDS, and the row pair 1 waves write their rows at the START of
