@@ -7,6 +7,7 @@
 * end-to-end keypoint IoU at 1376x376 against SURVEY 8(c)'s 0.98 bar, with the numbers written to the parity report.
 """
 import gc
+import os
 
 import numpy as np
 import pytest
@@ -332,3 +333,20 @@ def test_candidate_counters_survive_stage_benchmarks_and_batch_changes(weights_d
     got = feats()
     np.testing.assert_array_equal(ref[0], got[0]); np.testing.assert_array_equal(ref[1], got[1])
     sp.close()
+
+
+@pytest.mark.parametrize("calls,pairs", [(120, 1), (60, 5), (25, 32)])
+def test_repeated_calls_are_bit_identical(calls, pairs):
+    """Soak (scripts/dev/soak_determinism.py): the same front-end call on the same input, again and again - keypoints, counts, descriptors, matches and
+    scores must equal the first call's bit for bit.  The persistent kernels (ping-pong convolutions, the rolling-window conv2a -> conv2b kernel with its
+    producer / consumer rings and LDS-DMA, the two-stream LightGlue call) synchronise by barriers and counters; a hole in that shows up as a rare mismatch
+    here long before it turns a parity test red.  One pair per call runs the latency-mode kernels and ~500 row segments in the fused conv2 kernel, 5 and
+    32 pairs the throughput kernels with odd and even unit counts per workgroup."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "soak_determinism.py"), str(calls), str(pairs)], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    print(r.stdout[-400:])
+    assert r.returncode == 0 and "mismatching outputs: 0" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
