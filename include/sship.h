@@ -255,7 +255,9 @@ int sship_lg_debug_read(sship_lg* lg, int what, int index, int rows, int cols, f
 /* Test-only: copy one encoder activation of the extractor's LAST call to the host as raw fp16 (channels-last [batch][h_l][w_l][c_l]),
  * device-synchronising.  layer: 1 conv1b (+pool), 2 conv2a, 3 conv2b (+pool), 4 conv3a, 5 conv3b (+pool), 6 conv4a, 7 conv4b (the ids of
  * sship_sp_bench_layer).  Used by the parity suite to compare single layers (e.g. the Winograd variant of conv2a / conv2b) with a CPU
- * convolution of the previous layer's activation; the product never calls it.  `bytes` must not exceed the activation's size. */
+ * convolution of the previous layer's activation; the product never calls it.  `bytes` must not exceed the activation's size.
+ * Layer 2 (conv2a) is NOT materialised by the shipped library: conv2a -> conv2b -> pool run as one kernel whose intermediate map never leaves the CU
+ * (csrc/conv_fuse2.hip); its buffer holds the last two-launch run's map (developer build, SUPERSLAM_HIP_CONV2=split / SUPERSLAM_HIP_CONV64=wino) or nothing. */
 int sship_sp_debug_activation(sship_sp* sp, int layer, void* out_host, unsigned long long bytes);
 /* Match post-processing, src/LightGlue.cc:326-363: ascending i, skip -1, distance = 1 - score.
  * Returns the number of matches (>= 0). */
